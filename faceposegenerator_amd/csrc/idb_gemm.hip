@@ -1,0 +1,492 @@
+// K1/K2/K3 — implicit GEMM on MFMA for gfx950: conv3x3 (stride 1/2, nearest-2x upsample), 1x1 conv,
+// Linear, with skip-concat / fused-shortcut K segments and bias / temb / residual / GEGLU epilogues.
+//
+// Upstream ops replaced (see include/idb_kernels.h): diffusers ResnetBlock2D.conv1/conv2/conv_shortcut,
+// Downsample2D.conv, Upsample2D (interpolate + conv), Attention.to_q/k/v/to_out, FeedForward (GEGLU),
+// Transformer2DModel.proj_in/proj_out — reached from /root/reference/inference_ID-Booth.py:138.
+//
+// Design (MI355X):
+//   * NHWC activations: one K-step (64 channels of one tap) of an im2col row is ONE contiguous
+//     128-byte line, so both operands stream HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA,
+//     16 B/lane, no VGPR staging); zero padding = lanes pointed at a zero page.
+//   * LDS tile rows are 128 B; chunk c of row r is stored at chunk position c ^ (r & 7) (swizzle
+//     applied on the SOURCE address, LDS-DMA destinations are lane-linear) so every ds_read_b128
+//     fragment read is bank-conflict free.
+//   * v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate.  The weight fragment is the MFMA A operand
+//     and the activation fragment the B operand, so each lane ends up with 4 CONSECUTIVE output
+//     channels of one pixel -> 8-byte (bf16) / 16-byte (fp32) epilogue accesses.
+//   * double-buffered LDS, next tile's DMA issued before the current tile's MFMAs, one barrier
+//     per K-step; XCD-aware bijective block remap so blocks sharing an activation tile share an L2.
+//   * small-M layers (8x8 / 16x16 levels at batch 1) use split-K with fp32 slabs + a fused
+//     reduce/epilogue kernel (deterministic, no atomics).
+#include "idb_common.h"
+
+struct GemmSrcK {
+    const char* ptr;
+    int C, taps, H, W, up;
+};
+
+struct GemmParams {
+    GemmSrcK src[IDB_MAX_SRC];
+    int M, N, HW, OW, stride;
+    long long w_row_bytes;
+    int ktiles, kt_per_split, splitk;
+    const char* w;
+    const float* bias;
+    const float* sbias;
+    int sbias_ld;
+    const char* res;
+    void* out;
+    int out_ld, out_f32, geglu;
+    float scale;
+    float* partial;
+    const char* zero;
+    int tiles_n;
+};
+
+template <typename T, int MF, int NF>
+__global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
+    using V8 = typename Op<T>::v8;
+    constexpr int BM = 32 * MF, BN = 32 * NF, STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
+    // contiguous run of tiles so neighbours re-use the same activation rows from that L2.
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+    const int nk = kt1 - kt0;
+
+    // ---- per-thread staging coordinates: thread loads chunk position (tid&7) of rows (tid>>3)+32i
+    const int lrow = tid >> 3;
+    const int cg16 = ((tid & 7) ^ (lrow & 7)) * 16;   // source-side swizzle (bytes)
+    int a_b[MF], a_oy[MF], a_ox[MF];
+    bool a_ok[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + i * 32 + lrow;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        a_b[i] = mm / p.HW;
+        const int rem = mm - a_b[i] * p.HW;
+        a_oy[i] = rem / p.OW;
+        a_ox[i] = rem - a_oy[i] * p.OW;
+    }
+    const char* wp[NF];
+    int winc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int n = n0 + j * 32 + lrow;
+        const bool ok = n < p.N;
+        wp[j] = ok ? p.w + (long long)n * p.w_row_bytes + (long long)kt0 * 128 + cg16 : p.zero;
+        winc[j] = ok ? 128 : 0;
+    }
+
+    // ---- K-step state: source s, tap, channel offset c0
+    int s = 0, tap = 0, c0 = 0;
+    {
+        int rem = kt0;
+        while (s < IDB_MAX_SRC - 1) {
+            const int steps = p.src[s].taps * (p.src[s].C >> 6);
+            if (rem < steps) break;
+            rem -= steps;
+            ++s;
+        }
+        const int cs = p.src[s].C >> 6;
+        tap = rem / cs;
+        c0 = (rem - tap * cs) << 6;
+    }
+
+    auto stage = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + BM * 128;
+        const GemmSrcK S = p.src[s];
+        int dy = 0, dx = 0;
+        if (S.taps == 9) {
+            const int t3 = tap / 3;
+            dy = t3 - 1;
+            dx = tap - t3 * 3 - 1;
+        }
+        const int LH = S.H << S.up, LW = S.W << S.up;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
+            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;
+            const long long pix = ((long long)a_b[i] * S.H + (iy >> S.up)) * S.W + (ix >> S.up);
+            const char* g = ok ? S.ptr + (pix * S.C + c0) * 2 + cg16 : p.zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(sA + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(wp[j]), LDS_PTR(sB + (j * 256 + wave * 64) * 16), 16, 0, 0);
+            wp[j] += winc[j];
+        }
+        c0 += 64;
+        if (c0 == S.C) {
+            c0 = 0;
+            if (++tap == S.taps) {
+                tap = 0;
+                if (s < IDB_MAX_SRC - 1) ++s;
+            }
+        }
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nk) stage(cur ^ 1);
+        const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
+        const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pos = ((ks * 4 + fg) ^ (fr & 7)) * 16;
+            V8 af[MF], wf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const V8*)(sA + i * 16 * 128 + pos);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *(const V8*)(sB + j * 16 * 128 + pos);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds out[m][n .. n+3], m = tile row (lane&15), n = 4*(lane>>4) + reg
+    const bool vec_ok = (p.N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + (wm * MF + i) * 16 + fr;
+        if (m >= p.M) continue;
+        if (p.splitk > 1) {
+            float* dst = p.partial + ((long long)blockIdx.z * p.M + m) * p.N;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int n = n0 + (wn * NF + j) * 16 + fg * 4;
+                if (vec_ok && n + 3 < p.N) {
+                    *(f32x4*)(dst + n) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) dst[n + e] = acc[i][j][e];
+                }
+            }
+            continue;
+        }
+        const float* sb = p.sbias ? p.sbias + (long long)(m / p.HW) * p.sbias_ld : nullptr;
+        if (p.geglu) {
+            if constexpr ((NF & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < NF; j += 2) {
+                    const int nv = n0 + (wn * NF + j) * 16 + fg * 4;   // packed row of the value part
+                    if (nv >= p.N) continue;   // N % 32 == 0: a value/gate pair is in range or not as a whole
+                    const int oc = (n0 + (wn * NF + j) * 16) / 2 + fg * 4;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][e] * p.scale, gt = acc[i][j + 1][e] * p.scale;
+                        if (p.bias) {
+                            v += p.bias[nv + e];
+                            gt += p.bias[nv + 16 + e];
+                        }
+                        o[e] = v * gelu_erf_f(gt);
+                    }
+                    T* dst = (T*)p.out + (long long)m * p.out_ld + oc;
+                    typename Op<T>::v4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
+                    *(typename Op<T>::v4*)dst = pk;
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int n = n0 + (wn * NF + j) * 16 + fg * 4;
+            if (n >= p.N) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
+            if (vec_ok && n + 3 < p.N) {
+                if (p.bias) {
+                    const f32x4 b4 = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
+                }
+                if (sb) {
+                    const f32x4 b4 = *(const f32x4*)(sb + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
+                }
+                if (p.res) {
+                    const typename Op<T>::v4 r4 = *(const typename Op<T>::v4*)((const T*)p.res + (long long)m * p.out_ld + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += to_f32<T>(r4[e]);
+                }
+                if (p.out_f32) {
+                    *(f32x4*)((float*)p.out + (long long)m * p.out_ld + n) = (f32x4){o[0], o[1], o[2], o[3]};
+                } else {
+                    typename Op<T>::v4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
+                    *(typename Op<T>::v4*)((T*)p.out + (long long)m * p.out_ld + n) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.N) break;
+                    float v = o[e];
+                    if (p.bias) v += p.bias[n + e];
+                    if (sb) v += sb[n + e];
+                    if (p.res) v += to_f32<T>(((const T*)p.res)[(long long)m * p.out_ld + n + e]);
+                    if (p.out_f32) ((float*)p.out)[(long long)m * p.out_ld + n + e] = v;
+                    else ((T*)p.out)[(long long)m * p.out_ld + n + e] = from_f32<T>(v);
+                }
+            }
+        }
+    }
+}
+
+// Split-K tail: sum the fp32 slabs and apply the same epilogue (bias, per-sample bias, residual).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void idb_splitk_reduce_kernel(const float* __restrict__ partial, int splitk,
+                                                                int M, int N, int HW, float scale,
+                                                                const float* bias, const float* sbias, int sbias_ld,
+                                                                const T* res, void* out, int out_ld, int out_f32) {
+    const long long total = (long long)M * N / VEC;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long e0 = idx * VEC;
+    const int m = (int)(e0 / N), n = (int)(e0 - (long long)m * N);
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    for (int z = 0; z < splitk; ++z) {
+        const float* src = partial + ((long long)z * M + m) * N + n;
+        if constexpr (VEC == 4) {
+            const f32x4 t = *(const f32x4*)src;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += t[e];
+        } else {
+            v[0] += src[0];
+        }
+    }
+    const float* sb = sbias ? sbias + (long long)(m / HW) * sbias_ld : nullptr;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        v[e] *= scale;
+        if (bias) v[e] += bias[n + e];
+        if (sb) v[e] += sb[n + e];
+        if (res) v[e] += to_f32<T>(res[(long long)m * out_ld + n + e]);
+        if (out_f32) ((float*)out)[(long long)m * out_ld + n + e] = v[e];
+        else ((T*)out)[(long long)m * out_ld + n + e] = from_f32<T>(v[e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct TileCfg { int mf, nf; };
+const TileCfg kTiles[] = {{0, 0}, {4, 5}, {4, 4}, {2, 5}, {2, 4}, {4, 1}};   // index = desc.tile
+constexpr int kNumTiles = 5;
+
+struct Plan {
+    int tile, splitk, tiles_m, tiles_n, ktiles, kt_per_split, M;
+    long long K;
+};
+
+int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
+    IDB_REQUIRE(d != nullptr, "idb_gemm: null descriptor");
+    IDB_REQUIRE(idb_is_operand_dtype(d->dtype), "idb_gemm: dtype must be bf16 or f16 (got %d)", d->dtype);
+    IDB_REQUIRE(d->batch > 0 && d->out_h > 0 && d->out_w > 0 && d->n > 0, "idb_gemm: non-positive dims");
+    IDB_REQUIRE(d->stride == 1 || d->stride == 2, "idb_gemm: stride must be 1 or 2");
+    IDB_REQUIRE(d->nsrc >= 1 && d->nsrc <= IDB_MAX_SRC, "idb_gemm: nsrc out of range");
+    IDB_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == IDB_F32, "idb_gemm: out_dtype must be dtype or f32");
+    const long long M = (long long)d->batch * d->out_h * d->out_w;
+    IDB_REQUIRE(M < (1LL << 31), "idb_gemm: M too large");
+    long long K = 0;
+    for (int s = 0; s < d->nsrc; ++s) {
+        const idb_gemm_src& S = d->src[s];
+        IDB_REQUIRE(S.ptr != nullptr && idb_aligned16(S.ptr), "idb_gemm: src[%d] pointer null or not 16-byte aligned", s);
+        IDB_REQUIRE(S.channels > 0 && S.channels % 64 == 0, "idb_gemm: src[%d].channels=%d must be a multiple of 64", s, S.channels);
+        IDB_REQUIRE(S.taps == 9 || S.taps == 1, "idb_gemm: src[%d].taps must be 9 or 1", s);
+        IDB_REQUIRE(S.upsample == 0 || S.upsample == 1, "idb_gemm: src[%d].upsample must be 0/1", s);
+        IDB_REQUIRE(S.in_h > 0 && S.in_w > 0, "idb_gemm: src[%d] spatial dims", s);
+        const int lh = S.in_h << S.upsample, lw = S.in_w << S.upsample;
+        if (S.taps == 9) {
+            IDB_REQUIRE(d->out_h == (lh + d->stride - 1) / d->stride && d->out_w == (lw + d->stride - 1) / d->stride,
+                        "idb_gemm: src[%d] %dx%d (up=%d, stride=%d) does not produce %dx%d", s, S.in_h, S.in_w,
+                        S.upsample, d->stride, d->out_h, d->out_w);
+        } else {
+            IDB_REQUIRE(d->stride == 1 && lh == d->out_h && lw == d->out_w,
+                        "idb_gemm: 1x1 src[%d] must match the output grid", s);
+        }
+        K += (long long)S.taps * S.channels;
+    }
+    IDB_REQUIRE(d->w && idb_aligned16(d->w) && d->out && idb_aligned16(d->out), "idb_gemm: w/out null or unaligned");
+    IDB_REQUIRE(d->out_ld >= (d->geglu ? d->n / 2 : d->n), "idb_gemm: out_ld too small");
+    if (d->geglu) {
+        IDB_REQUIRE(d->n % 32 == 0 && d->out_dtype == d->dtype && !d->residual && !d->sample_bias,
+                    "idb_gemm: GEGLU needs n %% 32 == 0, operand-dtype output, no residual/sample_bias");
+        IDB_REQUIRE(d->out_ld % 4 == 0, "idb_gemm: GEGLU out_ld must be a multiple of 4");
+    }
+    if (d->n % 4 == 0) IDB_REQUIRE(d->out_ld % 4 == 0, "idb_gemm: out_ld must be a multiple of 4 when n is");
+    if (d->sample_bias) IDB_REQUIRE(d->sample_bias_ld == 0 || d->sample_bias_ld >= d->n, "idb_gemm: sample_bias_ld must be 0 (broadcast) or >= n");
+
+    pl->M = (int)M;
+    pl->K = K;
+    pl->ktiles = (int)(K / 64);
+    int tile = d->tile;
+    IDB_REQUIRE(tile >= 0 && tile <= kNumTiles, "idb_gemm: tile id out of range");
+    if (tile == 0) {
+        const bool n160 = (d->n % 160 == 0) && !d->geglu;
+        const int bn = d->n <= 32 ? 32 : (n160 ? 160 : 128);
+        const long long blocks_big = ((M + 127) / 128) * ((d->n + bn - 1) / bn);
+        if (d->n <= 32) tile = 5;
+        else if (blocks_big >= 200 || M > 4096) tile = n160 ? 1 : 2;
+        else tile = n160 ? 3 : 4;
+    }
+    if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
+    pl->tile = tile;
+    const int bm = 32 * kTiles[tile].mf, bn = 32 * kTiles[tile].nf;
+    pl->tiles_m = (int)((M + bm - 1) / bm);
+    pl->tiles_n = (d->n + bn - 1) / bn;
+    const long long blocks = (long long)pl->tiles_m * pl->tiles_n;
+    IDB_REQUIRE(blocks < (1LL << 31), "idb_gemm: grid too large");
+    int sk = d->split_k;
+    if (sk <= 0) {
+        sk = 1;
+        if (!d->geglu && blocks < 192 && pl->ktiles >= 16) {
+            sk = (int)((384 + blocks - 1) / blocks);
+            const int max_by_k = pl->ktiles / 8;
+            if (sk > max_by_k) sk = max_by_k;
+            if (sk > 32) sk = 32;
+            if (sk < 1) sk = 1;
+        }
+    }
+    IDB_REQUIRE(!(d->geglu && sk > 1), "idb_gemm: GEGLU does not support split-K");
+    if (sk > pl->ktiles) sk = pl->ktiles;
+    pl->kt_per_split = (pl->ktiles + sk - 1) / sk;
+    pl->splitk = (pl->ktiles + pl->kt_per_split - 1) / pl->kt_per_split;
+    return IDB_OK;
+}
+
+template <typename T, int MF, int NF>
+int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
+    constexpr int LDS = (32 * MF + 32 * NF) * 128 * 2;
+    static bool attr_done = false;
+    auto kern = idb_gemm_kernel<T, MF, NF>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            idb_set_error("idb_gemm: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
+            return IDB_EHIP;
+        }
+        attr_done = true;
+    }
+    dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, p);
+    IDB_CHECK_LAUNCH("idb_gemm");
+    return IDB_OK;
+}
+
+template <typename T>
+int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
+    int rc;
+    switch (pl.tile) {
+        case 1: rc = launch_tile<T, 4, 5>(p, pl, st); break;
+        case 2: rc = launch_tile<T, 4, 4>(p, pl, st); break;
+        case 3: rc = launch_tile<T, 2, 5>(p, pl, st); break;
+        case 4: rc = launch_tile<T, 2, 4>(p, pl, st); break;
+        default: rc = launch_tile<T, 4, 1>(p, pl, st); break;
+    }
+    if (rc != IDB_OK || pl.splitk == 1) return rc;
+    const int vec = (d->n % 4 == 0) ? 4 : 1;
+    const long long total = (long long)pl.M * d->n / vec;
+    const int blocks = (int)((total + 255) / 256);
+    if (vec == 4)
+        hipLaunchKernelGGL((idb_splitk_reduce_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, p.partial, pl.splitk, pl.M,
+                           d->n, p.HW, p.scale, p.bias, p.sbias, p.sbias_ld, (const T*)p.res, p.out, p.out_ld, p.out_f32);
+    else
+        hipLaunchKernelGGL((idb_splitk_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, p.partial, pl.splitk, pl.M,
+                           d->n, p.HW, p.scale, p.bias, p.sbias, p.sbias_ld, (const T*)p.res, p.out, p.out_ld, p.out_f32);
+    IDB_CHECK_LAUNCH("idb_splitk_reduce");
+    return IDB_OK;
+}
+
+}  // namespace
+
+extern "C" size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d) {
+    Plan pl;
+    if (plan_gemm(d, &pl) != IDB_OK) return 0;
+    return pl.splitk > 1 ? (size_t)pl.splitk * pl.M * d->n * sizeof(float) : 0;
+}
+
+extern "C" int idb_gemm_plan(const idb_gemm_desc* d, int32_t* tile, int32_t* split_k, int32_t* blocks) {
+    Plan pl;
+    int rc = plan_gemm(d, &pl);
+    if (rc != IDB_OK) return rc;
+    if (tile) *tile = pl.tile;
+    if (split_k) *split_k = pl.splitk;
+    if (blocks) *blocks = pl.tiles_m * pl.tiles_n * pl.splitk;
+    return IDB_OK;
+}
+
+extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    Plan pl;
+    int rc = plan_gemm(d, &pl);
+    if (rc != IDB_OK) return rc;
+    const size_t need = pl.splitk > 1 ? (size_t)pl.splitk * pl.M * d->n * sizeof(float) : 0;
+    IDB_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && idb_aligned16(workspace)),
+                "idb_gemm: workspace too small (%zu < %zu) or unaligned", workspace_bytes, need);
+    GemmParams p = {};
+    for (int s = 0; s < IDB_MAX_SRC; ++s) {
+        const idb_gemm_src& S = d->src[s < d->nsrc ? s : d->nsrc - 1];
+        p.src[s] = GemmSrcK{(const char*)S.ptr, S.channels, S.taps, S.in_h, S.in_w, S.upsample};
+    }
+    p.M = pl.M;
+    p.N = d->n;
+    p.HW = d->out_h * d->out_w;
+    p.OW = d->out_w;
+    p.stride = d->stride;
+    p.w_row_bytes = pl.K * 2;
+    p.ktiles = pl.ktiles;
+    p.kt_per_split = pl.kt_per_split;
+    p.splitk = pl.splitk;
+    p.w = (const char*)d->w;
+    p.bias = d->bias;
+    p.sbias = d->sample_bias;
+    p.sbias_ld = d->sample_bias_ld;
+    p.res = (const char*)d->residual;
+    p.out = d->out;
+    p.out_ld = d->out_ld;
+    p.out_f32 = d->out_dtype == IDB_F32;
+    p.geglu = d->geglu;
+    p.scale = d->out_scale == 0.f ? 1.f : d->out_scale;
+    p.partial = (float*)workspace;
+    p.zero = (const char*)idb_zero_page();
+    p.tiles_n = pl.tiles_n;
+    IDB_REQUIRE(p.zero != nullptr, "idb_gemm: zero page allocation failed");
+    hipStream_t st = (hipStream_t)stream;
+    return d->dtype == IDB_BF16 ? launch_all<__bf16>(d, p, pl, st) : launch_all<_Float16>(d, p, pl, st);
+}

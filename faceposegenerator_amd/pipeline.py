@@ -1,0 +1,243 @@
+"""API mirror of ``diffusers.StableDiffusionPipeline`` for the calls the reference makes.
+
+Reference usage reproduced (same names / kwargs / error behaviour):
+  * ``StableDiffusionPipeline.from_pretrained(path, torch_dtype=...)``, ``.to(device)``
+    (inference_ID-Booth.py:103) — LOCAL directory only, model names cannot be resolved offline;
+  * ``pipe.scheduler = DDPMScheduler.from_pretrained(path, subfolder="scheduler")`` (:104);
+  * ``pipe.load_lora_weights(dir)`` (:107), ``pipe.set_progress_bar_config(disable=True)`` (:108);
+  * ``pipe(prompt=..., negative_prompt=..., output_type="np", generator=..., num_inference_steps=30,
+    guidance_scale=5.0, width=512, height=512).images`` (:138);
+  * ``prompt_embeds`` / ``negative_prompt_embeds`` kwargs (train_ID-Booth.py:1221-1224);
+  * ``pipe.unet(x, t, ehs, return_dict=False)[0]`` (train_ID-Booth.py:1040-1046), ``pipe.vae.decode(z).sample``
+    (:412), ``pipe.vae.config.scaling_factor`` (:1002).
+
+Text conditioning (CLIP tokenizer + text encoder) is the "next" row of SURVEY.md §8f: this sampler
+takes ``prompt_embeds``; string prompts need an ``encode_prompt`` callable supplied by the caller.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Callable, List, Optional, Union
+
+import torch
+
+from . import spec as S
+from . import weights as W
+from .scheduler import DDPMScheduler
+
+
+class StableDiffusionPipelineOutput:
+    def __init__(self, images, nsfw_content_detected=None):
+        self.images = images
+        self.nsfw_content_detected = nsfw_content_detected
+
+
+class _DecoderOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class UNetHandle:
+    """``pipe.unet``: callable like UNet2DConditionModel for the kwargs the reference uses."""
+
+    def __init__(self, pipe: "StableDiffusionPipeline"):
+        self._pipe = pipe
+        self.config = SimpleNamespace(in_channels=pipe.unet_config.in_channels, sample_size=pipe.unet_config.sample_size,
+                                      time_cond_proj_dim=None, cross_attention_dim=pipe.unet_config.cross_attention_dim)
+
+    def __call__(self, sample, timestep, encoder_hidden_states, class_labels=None, return_dict: bool = True, **kw):
+        if class_labels is not None:
+            raise ValueError("class_labels are not supported (SD-2.1 has num_class_embeds = null)")
+        out = self._pipe._engine().unet_forward(sample, timestep, encoder_hidden_states)
+        return (out,) if not return_dict else SimpleNamespace(sample=out)
+
+
+class VAEHandle:
+    """``pipe.vae``: ``decode(z).sample`` and ``config.scaling_factor``."""
+
+    def __init__(self, pipe: "StableDiffusionPipeline"):
+        self._pipe = pipe
+        self.config = SimpleNamespace(scaling_factor=pipe.vae_config.scaling_factor,
+                                      latent_channels=pipe.vae_config.latent_channels)
+
+    def decode(self, z, return_dict: bool = True, **kw):
+        out = self._pipe._engine().vae_decode(z)
+        return (out,) if not return_dict else _DecoderOutput(out)
+
+
+class StableDiffusionPipeline:
+    def __init__(self, unet_config: S.UNetConfig, vae_config: S.VAEConfig, unet_sd, vae_sd,
+                 scheduler: Optional[DDPMScheduler] = None, torch_dtype=None, encode_prompt: Optional[Callable] = None):
+        self.unet_config, self.vae_config = unet_config, vae_config
+        self._unet_sd, self._vae_sd = unet_sd, vae_sd
+        self.scheduler = scheduler or DDPMScheduler(S.SchedulerConfig(prediction_type=unet_config.prediction_type))
+        self.dtype_name = {None: "bf16", torch.bfloat16: "bf16", torch.float16: "f16", "bf16": "bf16", "f16": "f16"}.get(torch_dtype)
+        if self.dtype_name is None:
+            raise ValueError(f"torch_dtype {torch_dtype} unsupported: use torch.bfloat16 or torch.float16")
+        self.device = torch.device("cpu")
+        self._eng = None
+        self._lora = None
+        self._progress = {}
+        self.encode_prompt_fn = encode_prompt
+        self.use_graph = True
+        self.vae_chunk = 4
+        self.unet = UNetHandle(self)
+        self.vae = VAEHandle(self)
+        self.vae_scale_factor = 2 ** (len(vae_config.block_out_channels) - 1)
+
+    # ---- construction -----------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, torch_dtype=None, **kw) -> "StableDiffusionPipeline":
+        root = pretrained_model_name_or_path
+        if not os.path.isdir(root):
+            raise FileNotFoundError(f"{root!r} is not a local directory; model names cannot be resolved offline "
+                                    f"(expected the diffusers layout: model_index.json, unet/, vae/, scheduler/)")
+        ucfg, vcfg = W.load_unet_config(root), W.load_vae_config(root)
+        scfg = W.load_scheduler_config(root)
+        ucfg = S.UNetConfig(**{**ucfg.__dict__, "prediction_type": scfg.prediction_type})
+        return cls(ucfg, vcfg, W.load_unet_weights(root), W.load_vae_decoder_weights(root), DDPMScheduler(scfg), torch_dtype)
+
+    @classmethod
+    def from_synthetic(cls, unet_config: S.UNetConfig = S.SD21_UNET, vae_config: S.VAEConfig = S.SD21_VAE,
+                       seed: int = 1234, torch_dtype=None) -> "StableDiffusionPipeline":
+        """Seeded random weights of the published shapes (there is no network for checkpoints)."""
+        return cls(unet_config, vae_config, W.synth_unet(unet_config, seed), W.synth_vae(vae_config, seed + 1),
+                   torch_dtype=torch_dtype)
+
+    def to(self, device) -> "StableDiffusionPipeline":
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise ValueError("this pipeline runs on an MI355X only (device must be 'cuda:N'); there is no CPU path")
+        if self._eng is not None and device != self.device:
+            self._eng = None
+        self.device = device
+        return self
+
+    def _engine(self):
+        if self._eng is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("call .to('cuda:0') first: the sampler has no CPU path")
+            from .engine import HipEngine          # raises loudly if the HIP library is missing
+            self._eng = HipEngine(self.unet_config, self.vae_config, self._unet_sd, self._vae_sd, self.device, self.dtype_name)
+            if self._lora is not None:
+                self._eng.set_lora(*self._lora)
+        return self._eng
+
+    def set_progress_bar_config(self, **kwargs) -> None:
+        self._progress = dict(kwargs)
+
+    # ---- LoRA -------------------------------------------------------------------------
+    def load_lora_weights(self, pretrained_model_name_or_path_or_dict, weight_name: str = "pytorch_lora_weights.safetensors",
+                          **kw) -> None:
+        src = pretrained_model_name_or_path_or_dict
+        if isinstance(src, dict):
+            tensors, alphas = W.normalize_lora_keys(src), {}
+        else:
+            if not os.path.exists(src):
+                raise FileNotFoundError(f"LoRA checkpoint {src!r} not found (local paths only)")
+            tensors, alphas = W.load_lora(src, weight_name)
+        if not tensors:
+            raise ValueError("no UNet LoRA tensors found in the checkpoint")
+        self._lora = (tensors, 1.0, alphas)
+        if self._eng is not None:
+            self._eng.set_lora(*self._lora)
+
+    def unload_lora_weights(self) -> None:
+        self._lora = None
+        if self._eng is not None:
+            self._eng.set_lora(None)
+
+    # ---- sampling ---------------------------------------------------------------------
+    def check_inputs(self, prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds):
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one of the two.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both undefined.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, "
+                             f"but got {tuple(prompt_embeds.shape)} != {tuple(negative_prompt_embeds.shape)}.")
+
+    def _encode(self, prompt, negative_prompt, do_cfg):
+        if self.encode_prompt_fn is None:
+            raise NotImplementedError(
+                "string prompts need a text encoder: pass `prompt_embeds`/`negative_prompt_embeds` "
+                "(train_ID-Booth.py:1221-1224 style) or construct the pipeline with encode_prompt=callable "
+                "(CLIP text conditioning is the next row of the build plan, SURVEY.md §8f-1)")
+        return self.encode_prompt_fn(prompt, negative_prompt, do_cfg)
+
+    def prepare_noise(self, batch: int, steps: int, height: int, width: int, generator) -> torch.Tensor:
+        """RNG order of the upstream pipeline with a CPU generator (randn_tensor draws on the generator's
+        device): initial latents, then one draw per step including the last (t=1 > 0).  A list of
+        generators gives one stream per sample, as upstream.  Returns [steps+1, B, C, h, w] fp32 (host)."""
+        lc = self.unet_config.in_channels
+        h, w_ = height // self.vae_scale_factor, width // self.vae_scale_factor
+        if isinstance(generator, (list, tuple)):
+            if len(generator) != batch:
+                raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                                 f"effective batch size of {batch}.")
+            draws = []
+            for _ in range(steps + 1):
+                draws.append(torch.cat([torch.randn((1, lc, h, w_), generator=g, device=g.device, dtype=torch.float32).cpu()
+                                        for g in generator]))
+            return torch.stack(draws)
+        gdev = generator.device if generator is not None else torch.device("cpu")
+        return torch.stack([torch.randn((batch, lc, h, w_), generator=generator, device=gdev, dtype=torch.float32).cpu()
+                            for _ in range(steps + 1)])
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str], None] = None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 7.5, negative_prompt=None,
+                 num_images_per_prompt: int = 1, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 output_type: str = "pil", return_dict: bool = True, noise: Optional[torch.Tensor] = None, **kw):
+        height = height or self.unet_config.sample_size * self.vae_scale_factor
+        width = width or self.unet_config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        if output_type not in ("np", "pt", "latent", "pil", "uint8"):
+            raise ValueError(f"output_type {output_type!r} not supported")
+        do_cfg = guidance_scale > 1.0
+        if prompt_embeds is None:
+            prompt_embeds, negative_prompt_embeds = self._encode(prompt, negative_prompt, do_cfg)
+        if do_cfg and negative_prompt_embeds is None:
+            raise ValueError("guidance_scale > 1 needs `negative_prompt_embeds` (or a negative prompt with a text encoder)")
+        if num_images_per_prompt != 1:
+            prompt_embeds = prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+            if negative_prompt_embeds is not None:
+                negative_prompt_embeds = negative_prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        B = prompt_embeds.shape[0]
+        eng = self._engine()
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps)
+        timesteps = sch.timesteps.tolist()
+        if noise is None:
+            noise = self.prepare_noise(B, num_inference_steps, height, width, generator)
+        if latents is not None:
+            noise = noise.clone()
+            noise[0] = latents.float().cpu() * sch.init_noise_sigma
+        coefs = torch.tensor([list(sch.step_coefficients(t)) + [float(guidance_scale)] for t in timesteps], dtype=torch.float32)
+        lat = eng.sample(prompt_embeds, negative_prompt_embeds if do_cfg else None, noise.to(self.device), timesteps,
+                         coefs.to(self.device), vpred=(sch.config.prediction_type == "v_prediction"),
+                         use_graph=self.use_graph)
+        if output_type == "latent":
+            images = lat
+        else:
+            img01, u8 = eng.decode_images(lat, chunk=self.vae_chunk, want_u8=True)
+            if output_type == "np":
+                images = img01.cpu().numpy()                       # NHWC float32 in [0,1]
+            elif output_type == "pt":
+                images = img01.permute(0, 3, 1, 2).contiguous()
+            elif output_type == "uint8":
+                images = u8
+            else:
+                from PIL import Image
+                images = [Image.fromarray(a) for a in u8.cpu().numpy()]
+        if not return_dict:
+            return (images, None)
+        return StableDiffusionPipelineOutput(images=images, nsfw_content_detected=None)

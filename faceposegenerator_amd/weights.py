@@ -1,0 +1,214 @@
+"""Weights: seeded synthetic factory and local-directory I/O in the diffusers on-disk layout.
+
+The reference loads weights by model NAME (`inference_ID-Booth.py:103`) and LoRA checkpoints from
+`Trained_LoRA_Models/<model>/<ID>/checkpoint-31-6400` (`inference_ID-Booth.py:52-54,98,107`);
+neither is available offline, so benchmarks and tests use seeded synthetic tensors of the exact
+published shapes, and real weights can be read from a LOCAL directory only.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import asdict
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import spec as S
+
+SD = Dict[str, torch.Tensor]
+
+
+def _gen(seed: int, index: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((seed * 1000003 + index * 7919 + 17) % (2 ** 63 - 1))
+    return g
+
+
+def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, rich: bool = True) -> SD:
+    """N(0, 1/fan_in) matrices; with ``rich`` non-trivial biases and norm affine parameters so
+    that every epilogue path is exercised.  Each tensor has its own generator (seed, index in
+    sorted key order), so generation order does not matter and results are version-stable
+    (torch's CPU mt19937 stream)."""
+    sd: SD = {}
+    for i, name in enumerate(sorted(shapes)):
+        shape = shapes[name]
+        g = _gen(seed, i)
+        if name.endswith(".weight") and len(shape) >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            sd[name] = torch.randn(shape, generator=g, dtype=torch.float32) * (fan_in ** -0.5)
+        elif name.endswith(".weight"):               # norm gamma
+            sd[name] = (0.8 + 0.4 * torch.rand(shape, generator=g)) if rich else torch.ones(shape)
+        else:                                        # biases / norm beta
+            sd[name] = 0.05 * torch.randn(shape, generator=g) if rich else torch.zeros(shape)
+    return sd
+
+
+def synth_unet(cfg: S.UNetConfig = S.SD21_UNET, seed: int = 1234) -> SD:
+    return synth_state_dict(S.unet_param_shapes(cfg), seed)
+
+
+def synth_vae(cfg: S.VAEConfig = S.SD21_VAE, seed: int = 4321) -> SD:
+    return synth_state_dict(S.vae_decoder_param_shapes(cfg), seed)
+
+
+def synth_lora(cfg: S.UNetConfig = S.SD21_UNET, seed: int = 1, rank: int = 4, dialect: str = "diffusers") -> SD:
+    """A ~ N(0, 1/r) (PEFT 'gaussian' init, train_ID-Booth.py:675); B ~ N(0, 0.02) so that the
+    branch is non-zero.  Keys in the dialect the reference writes (train_ID-Booth.py:705)."""
+    shapes = S.lora_param_shapes(cfg, rank)
+    sd: SD = {}
+    for i, name in enumerate(sorted(shapes)):
+        g = _gen(seed + 77, i)
+        std = (1.0 / rank) if ".down." in name else 0.02
+        t = torch.randn(shapes[name], generator=g, dtype=torch.float32) * std
+        if dialect == "peft":
+            name = name.replace(".lora.down.weight", ".lora_A.weight").replace(".lora.up.weight", ".lora_B.weight")
+        sd[name] = t
+    return sd
+
+
+def normalize_lora_keys(raw: SD) -> SD:
+    """Both dialects -> ``<module path>.lora_A/lora_B.weight`` without the ``unet.`` prefix
+    (what diffusers' ``load_lora_weights`` does before injecting PEFT layers)."""
+    out: SD = {}
+    for k, v in raw.items():
+        if k.startswith("text_encoder."):
+            continue      # no text-encoder LoRA in the reference runs (configs/config_train_SD21.py:72)
+        if k.startswith("unet."):
+            k = k[len("unet."):]
+        k = k.replace(".lora.down.weight", ".lora_A.weight").replace(".lora.up.weight", ".lora_B.weight")
+        k = k.replace(".lora_A.default.weight", ".lora_A.weight").replace(".lora_B.default.weight", ".lora_B.weight")
+        out[k] = v.float()
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# On-disk layout: model dir + LoRA checkpoint dir
+# --------------------------------------------------------------------------------------
+def save_model_dir(root: str, unet_sd: SD, vae_sd: SD, ucfg: S.UNetConfig, vcfg: S.VAEConfig,
+                   scfg: S.SchedulerConfig = S.SD21_SCHED) -> None:
+    from safetensors.torch import save_file
+    for sub in ("unet", "vae", "scheduler"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    with open(os.path.join(root, "model_index.json"), "w") as f:
+        json.dump({"_class_name": "StableDiffusionPipeline",
+                   "unet": ["diffusers", "UNet2DConditionModel"],
+                   "vae": ["diffusers", "AutoencoderKL"],
+                   "scheduler": ["diffusers", "PNDMScheduler"]}, f, indent=1)
+    ucfg_d = {"_class_name": "UNet2DConditionModel", "in_channels": ucfg.in_channels,
+              "out_channels": ucfg.out_channels, "sample_size": ucfg.sample_size,
+              "block_out_channels": list(ucfg.block_out_channels),
+              "attention_head_dim": list(ucfg.num_heads),
+              "down_block_types": ["CrossAttnDownBlock2D" if a else "DownBlock2D" for a in ucfg.down_has_attn],
+              "up_block_types": ["CrossAttnUpBlock2D" if a else "UpBlock2D" for a in ucfg.up_has_attn],
+              "layers_per_block": ucfg.layers_per_block, "cross_attention_dim": ucfg.cross_attention_dim,
+              "norm_num_groups": ucfg.norm_num_groups, "norm_eps": ucfg.norm_eps,
+              "use_linear_projection": True, "act_fn": "silu", "flip_sin_to_cos": True, "freq_shift": 0}
+    with open(os.path.join(root, "unet", "config.json"), "w") as f:
+        json.dump(ucfg_d, f, indent=1)
+    vcfg_d = {"_class_name": "AutoencoderKL", "latent_channels": vcfg.latent_channels,
+              "out_channels": vcfg.out_channels, "block_out_channels": list(vcfg.block_out_channels),
+              "layers_per_block": vcfg.layers_per_block, "norm_num_groups": vcfg.norm_num_groups,
+              "scaling_factor": vcfg.scaling_factor, "act_fn": "silu"}
+    with open(os.path.join(root, "vae", "config.json"), "w") as f:
+        json.dump(vcfg_d, f, indent=1)
+    with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump(dict(asdict(scfg), _class_name="PNDMScheduler", trained_betas=None), f, indent=1)
+    save_file({k: v.contiguous() for k, v in unet_sd.items()},
+              os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+    save_file({k: v.contiguous() for k, v in vae_sd.items()},
+              os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+
+
+def _read_json(path: str) -> dict:
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    with open(path) as f:
+        return json.load(f)
+
+
+def load_unet_config(root: str) -> S.UNetConfig:
+    d = _read_json(os.path.join(root, "unet", "config.json"))
+    boc = tuple(d["block_out_channels"])
+    heads = d.get("attention_head_dim", 8)
+    heads = tuple(heads) if isinstance(heads, (list, tuple)) else (heads,) * len(boc)
+    return S.UNetConfig(in_channels=d.get("in_channels", 4), out_channels=d.get("out_channels", 4),
+                        sample_size=d.get("sample_size", 64), block_out_channels=boc, num_heads=heads,
+                        down_has_attn=tuple(t.startswith("CrossAttn") for t in d["down_block_types"]),
+                        layers_per_block=d.get("layers_per_block", 2),
+                        cross_attention_dim=d.get("cross_attention_dim", 1024),
+                        norm_num_groups=d.get("norm_num_groups", 32), norm_eps=d.get("norm_eps", 1e-5),
+                        time_proj_dim=boc[0])
+
+
+def load_vae_config(root: str) -> S.VAEConfig:
+    d = _read_json(os.path.join(root, "vae", "config.json"))
+    return S.VAEConfig(latent_channels=d.get("latent_channels", 4), out_channels=d.get("out_channels", 3),
+                       block_out_channels=tuple(d["block_out_channels"]),
+                       layers_per_block=d.get("layers_per_block", 2),
+                       norm_num_groups=d.get("norm_num_groups", 32),
+                       scaling_factor=d.get("scaling_factor", 0.18215))
+
+
+def load_scheduler_config(root: str, subfolder: Optional[str] = "scheduler") -> S.SchedulerConfig:
+    p = os.path.join(root, subfolder) if subfolder else root
+    d = _read_json(os.path.join(p, "scheduler_config.json"))
+    # DDPMScheduler.from_pretrained on a PNDM config keeps the shared keys and takes DDPM-class
+    # defaults for the rest.
+    return S.SchedulerConfig(num_train_timesteps=d.get("num_train_timesteps", 1000),
+                             beta_start=d.get("beta_start", 0.00085), beta_end=d.get("beta_end", 0.012),
+                             beta_schedule=d.get("beta_schedule", "scaled_linear"),
+                             prediction_type=d.get("prediction_type", "epsilon"),
+                             clip_sample=d.get("clip_sample", False),
+                             steps_offset=d.get("steps_offset", 1))
+
+
+def _load_safetensors(path: str) -> SD:
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    from safetensors.torch import load_file
+    return {k: v.float() for k, v in load_file(path).items()}
+
+
+def load_unet_weights(root: str) -> SD:
+    return _load_safetensors(os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+
+
+def load_vae_decoder_weights(root: str) -> SD:
+    raw = _load_safetensors(os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+    out: SD = {}
+    for k, v in raw.items():
+        if k.startswith("encoder.") or k.startswith("quant_conv."):
+            continue
+        if ".attentions.0." in k:                       # legacy names, Appendix B
+            for old, new in S.VAE_LEGACY_ATTN_KEYS.items():
+                k = k.replace(f".attentions.0.{old}.", f".attentions.0.{new}.")
+            if k.endswith(".weight") and v.ndim == 4:   # very old checkpoints store 1x1 convs
+                v = v[:, :, 0, 0]
+        out[k] = v
+    return out
+
+
+def save_lora(path_or_dir: str, lora_sd: SD, weight_name: str = "pytorch_lora_weights.safetensors") -> str:
+    from safetensors.torch import save_file
+    path = path_or_dir
+    if not path.endswith(".safetensors"):
+        os.makedirs(path_or_dir, exist_ok=True)
+        path = os.path.join(path_or_dir, weight_name)
+    save_file({k: v.contiguous() for k, v in lora_sd.items()}, path)
+    return path
+
+
+def load_lora(path_or_dir: str, weight_name: str = "pytorch_lora_weights.safetensors") -> Tuple[SD, Dict[str, float]]:
+    """Returns (normalized tensors, per-module alpha).  No alpha entries => alpha = rank => scale 1
+    (what the reference's checkpoints contain)."""
+    path = path_or_dir
+    if os.path.isdir(path_or_dir):
+        path = os.path.join(path_or_dir, weight_name)
+    raw = _load_safetensors(path)
+    alphas = {k[len("unet."):-len(".alpha")] if k.startswith("unet.") else k[:-len(".alpha")]: float(v)
+              for k, v in raw.items() if k.endswith(".alpha")}
+    tensors = normalize_lora_keys({k: v for k, v in raw.items() if not k.endswith(".alpha")})
+    return tensors, alphas

@@ -1,0 +1,171 @@
+/*
+ * idb_kernels.h — C ABI of libidb_kernels.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * ID-Booth sampling path (SD-2.1 UNet forward, CFG + DDPM step, VAE decode).
+ *
+ * The reference has no FFI for this path: it is a Python object protocol
+ * (diffusers.StableDiffusionPipeline, /root/reference/inference_ID-Booth.py:103-108,138), and every
+ * arithmetic step is dispatched by torch/cuDNN/cuBLAS inside un-vendored diffusers.  Each entry point
+ * below therefore cites the upstream op it replaces and the reference call
+ * site that reaches it.  INTEGRATION.md shows the ctypes binding a maintainer of the reference adds.
+ *
+ * Conventions:
+ *   - plain C types only; device pointers are void*; `stream` is a hipStream_t passed as void*;
+ *   - every function returns 0 (IDB_OK) or a negative idb_status; idb_last_error() gives the text
+ *     (thread-local);
+ *   - no ownership transfer: the caller allocates inputs, outputs and workspaces;
+ *   - kernels are asynchronous on `stream` and never synchronise (graph-capturable);
+ *   - activations are NHWC ("channels-last") in the operand dtype (bf16 or f16), so a [B,H,W,C]
+ *     feature map and a [B, H*W, C] token matrix are the same bytes;
+ *   - weights are [N][K] row-major in the operand dtype (torch Linear convention); conv weights are
+ *     repacked to [Cout][tap][Cin] by idb_pack_conv_weight.
+ */
+#ifndef IDB_KERNELS_H
+#define IDB_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { IDB_OK = 0, IDB_EINVAL = -1, IDB_EUNSUPPORTED = -2, IDB_EHIP = -3 } idb_status;
+typedef enum { IDB_BF16 = 0, IDB_F16 = 1, IDB_F32 = 2 } idb_dtype;
+
+#define IDB_MAX_SRC 4
+
+int idb_version(void);
+const char* idb_last_error(void);
+/* 0 iff `device` is a gfx950 part (the only target this library is built for). */
+int idb_device_check(int device);
+
+/* ------------------------------------------------------------------------------------------
+ * K1/K2/K3 — implicit GEMM:  out[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue)
+ *
+ * Replaces: nn.Conv2d 3x3 (stride 1/2, pad 1), nearest-2x upsample + conv, 1x1 conv_shortcut,
+ * nn.Linear, GEGLU — i.e. diffusers ResnetBlock2D / Downsample2D / Upsample2D / Attention.to_* /
+ * FeedForward as dispatched from UNet2DConditionModel.forward (inference_ID-Booth.py:138,
+ * train_ID-Booth.py:1040-1046) and Decoder.forward (train_ID-Booth.py:410-412).
+ *
+ * A is never materialised: row m = output pixel (b, oy, ox); the K axis is the concatenation of up
+ * to IDB_MAX_SRC sources, each contributing taps*channels columns ordered [tap][channel]:
+ *   taps = 9 : 3x3 window with zero padding 1 read from an NHWC tensor [batch][in_h][in_w][channels]
+ *              (upsample = 1: the tensor is logically nearest-2x upsampled first);
+ *   taps = 1 : the pixel itself (1x1 conv, or a plain [M][K] matrix with in_h = in_w = 1).
+ * Several sources give skip-concatenation and the fused 1x1 shortcut without a concat pass.
+ * channels must be a multiple of 64 for every source.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* ptr;
+    int32_t channels;
+    int32_t taps;      /* 9 or 1 */
+    int32_t in_h, in_w;
+    int32_t upsample;  /* 0 or 1 */
+} idb_gemm_src;
+
+typedef struct {
+    int32_t dtype;            /* IDB_BF16 or IDB_F16: operand dtype of A, W, residual */
+    int32_t batch, out_h, out_w;   /* M = batch*out_h*out_w */
+    int32_t stride;           /* 1 or 2, applies to taps=9 sources */
+    int32_t n;                /* rows of W (before GEGLU halving) */
+    int32_t nsrc;
+    idb_gemm_src src[IDB_MAX_SRC];
+    const void* w;            /* [n][K] */
+    const float* bias;        /* [n] or NULL */
+    const float* sample_bias; /* [batch][sample_bias_ld] added per sample (temb projection) or NULL */
+    int32_t sample_bias_ld;   /* 0 = the same row for every sample */
+    const void* residual;     /* [M][out_ld] operand dtype, or NULL */
+    int32_t geglu;            /* 1: W rows interleaved by idb_pack_matrix(geglu=1); out has n/2 cols */
+    void* out;
+    int32_t out_dtype;        /* IDB_BF16/IDB_F16 (== dtype) or IDB_F32 */
+    int32_t out_ld;           /* elements between output rows */
+    int32_t split_k;          /* 0 = library heuristic, >=1 explicit */
+    int32_t tile;             /* 0 = heuristic; else 1..5 selects a tile config (see idb_gemm_plan) */
+    float out_scale;          /* multiplies the accumulator before bias (0 => 1.0) */
+} idb_gemm_desc;
+
+size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);
+/* What idb_gemm would launch for `d`: tile config id (1: 128x160, 2: 128x128, 3: 64x160, 4: 64x128,
+ * 5: 128x32), split-K factor and workgroup count.  Host-only, no GPU call. */
+int idb_gemm_plan(const idb_gemm_desc* d, int32_t* tile, int32_t* split_k, int32_t* blocks);
+int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Weight packing (run once at load; SURVEY.md §8b "idb_pack_*"). src is fp32 in torch layout. */
+/* [Cout][Cin][kh][kw] fp32 -> [Cout][kh*kw][Cin] operand dtype. */
+int idb_pack_conv_weight(const float* src, void* dst, int32_t cout, int32_t cin, int32_t ktaps,
+                         int32_t dtype, void* stream);
+/* [rows][cols] fp32 -> operand dtype, optional GEGLU row interleave (value/gate in 16-row groups). */
+int idb_pack_matrix(const float* src, void* dst, int64_t rows, int64_t cols, int32_t geglu,
+                    int32_t dtype, void* stream);
+/* dst[rows][cols] = W + scale * B[rows][r] * A[r][cols], fp32 in, operand dtype out: merged LoRA
+ * (peft lora.Linear with merged weights; inference_ID-Booth.py:107). */
+int idb_lora_merge(const float* w, const float* lora_a, const float* lora_b, void* dst, int64_t rows,
+                   int64_t cols, int32_t rank, float scale, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1 (norm part) / K6 — GroupNorm and LayerNorm.
+ * Replaces nn.GroupNorm(32, C) (+ SiLU) of ResnetBlock2D / Transformer2DModel.norm / conv_norm_out
+ * and nn.LayerNorm(C) x3 of BasicTransformerBlock.
+ * GroupNorm input may be the channel-concatenation of two NHWC tensors (skip connections); the
+ * output is one dense [B][HW][C0+C1] tensor.  Statistics are fp32, deterministic (no atomics).
+ * ------------------------------------------------------------------------------------------ */
+size_t idb_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups);
+int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw,
+                  int32_t groups, float eps, const float* gamma, const float* beta, int32_t silu,
+                  void* out, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+int idb_layernorm(const void* x, void* out, int64_t rows, int32_t c, float eps, const float* gamma,
+                  const float* beta, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4/K5 — fused attention, head_dim 64: out = softmax(Q K^T * scale) V, online softmax in fp32.
+ * Replaces F.scaled_dot_product_attention in AttnProcessor2_0 (self- and cross-attention).
+ * q: [batch][n_q][heads*64] with row stride q_ld; k, v: [batch][n_kv_alloc][...] with row stride
+ * kv_ld (n_kv_alloc rows allocated per batch entry, only the first n_kv are attended).
+ * ------------------------------------------------------------------------------------------ */
+int idb_attention(const void* q, int32_t q_ld, const void* k, const void* v, int32_t kv_ld,
+                  void* out, int32_t out_ld, int32_t batch, int32_t heads, int32_t n_q, int32_t n_kv,
+                  int32_t n_kv_alloc, float scale, int32_t dtype, void* stream);
+/* In-place row softmax over [rows][cols] (VAE mid-block single-head attention, d = 512). */
+int idb_softmax_rows(void* x, int64_t rows, int32_t cols, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7 — time embedding path in fp32: y = act_in(x) W^T + b for tiny M (30 timesteps).
+ * Replaces Timesteps/TimestepEmbedding and ResnetBlock2D.time_emb_proj.
+ * ------------------------------------------------------------------------------------------ */
+int idb_timestep_sinusoid(const float* timesteps, float* out, int32_t n, int32_t dim, void* stream);
+int idb_linear_f32(const float* x, const float* w, const float* bias, float* y, int32_t m, int32_t n,
+                   int32_t k, int32_t silu_in, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * conv_in (Cin = 4): fp32 NCHW latents -> operand-dtype NHWC features; `rep` replicates the batch
+ * (CFG feeds the same latents twice).  Replaces UNet conv_in / VAE post_quant_conv + conv_in.
+ * ------------------------------------------------------------------------------------------ */
+int idb_conv_in(const float* x_nchw, const float* w, const float* bias, void* out, int32_t batch,
+                int32_t rep, int32_t cin, int32_t h, int32_t w_, int32_t cout, float in_scale,
+                const float* pre_w, const float* pre_b, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8 — classifier-free guidance + DDPMScheduler.step, fp32 (inference_ID-Booth.py:104,138;
+ * train_ID-Booth.py:1081).  eps is [2B][HW][C] fp32 (uncond first); latents/noise are NCHW fp32.
+ * coef points at 6 floats on the DEVICE: {sqrt_alpha_bar_t, sqrt_beta_bar_t, c_x0, c_x, sigma,
+ * guidance_scale}; prediction_type 0 = epsilon, 1 = v_prediction.  x0_out may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+int idb_cfg_ddpm_step(const float* eps, float* latents, const float* noise, const float* coef,
+                      float* x0_out, int32_t batch, int32_t channels, int32_t hw, int32_t cfg,
+                      int32_t prediction_type, void* stream);
+
+/* K10 — VaeImageProcessor.postprocess + save_image quantisation:
+ * x [B][HW][C] fp32 -> img01 = clamp(x/2+0.5,0,1) (fp32 NHWC, may be NULL) and u8 = floor(255*img01+0.5). */
+int idb_postprocess(const float* x, float* img01, uint8_t* u8, int64_t count, void* stream);
+
+/* [B][HW][C] operand dtype -> [B][C][HW] fp32 (API boundary: unet(...)[0], vae.decode(...).sample). */
+int idb_nhwc_to_nchw_f32(const void* x, float* out, int32_t batch, int32_t hw, int32_t c, int32_t dtype,
+                         void* stream);
+int idb_f32_nhwc_to_nchw(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, void* stream);
+/* [rows][cols] fp32 -> operand dtype (prompt embeddings). */
+int idb_cast_f32(const float* x, void* out, int64_t count, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,323 @@
+"""GPU parity tests of each C-ABI kernel against plain torch fp32 ops on the SAME (operand-dtype-rounded)
+inputs.  Tolerances: the kernels accumulate in fp32 and round the output once to bf16 (2^-9 relative) or
+f16 (2^-11), so errors are bounded by a few output ulps plus fp32 accumulation-order noise."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", params=["bf16", "f16"])
+def eng(request, lib):
+    from faceposegenerator_amd import spec as S
+    from faceposegenerator_amd.engine import HipEngine
+    return HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, DEV, request.param)
+
+
+def _rt(eng, x):
+    """round-trip through the operand dtype (what the kernel sees), back to fp32"""
+    return x.to(eng.tdt).float()
+
+
+def _tol(eng, scale=1.0):
+    return (2.0 ** -7 if eng.dtype_name == "bf16" else 2.0 ** -9) * scale
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(DEV)
+
+
+def _check(out, ref, tol, what=""):
+    err = (out.float() - ref).abs().max().item()
+    mag = ref.abs().max().item()
+    assert err <= tol * max(1.0, mag), f"{what}: max err {err:.4e} vs tol {tol * max(1.0, mag):.4e} (|ref| max {mag:.3f})"
+
+
+# ---------------------------------------------------------------------------------------------------
+# implicit GEMM
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k,tile,split_k", [
+    (256, 320, 320, 1, 1), (300, 128, 64, 2, 1), (128, 160, 1280, 3, 4), (77, 256, 1024, 4, 3),
+    (1000, 4, 576, 5, 1), (64, 3, 128, 5, 2), (512, 640, 2560, 0, 0), (4096, 960, 320, 0, 0), (130, 1280, 1280, 0, 0)])
+def test_gemm_linear(eng, m, n, k, tile, split_k):
+    a = _rand((m, k), 1).to(eng.tdt)
+    w = _rand((n, k), 2, k ** -0.5).to(eng.tdt)
+    bias = _rand((n,), 3)
+    res = _rand((m, n), 4).to(eng.tdt) if n % 4 == 0 else None
+    ref = a.float() @ w.float().t() + bias + (res.float() if res is not None else 0)
+    out = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, m, 1, 1, bias=bias, residual=res, tile=tile, split_k=split_k)
+    torch.cuda.synchronize()
+    _check(out, ref, _tol(eng), f"linear {m}x{n}x{k}")
+    out32 = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, m, 1, 1, bias=bias, out_f32=True, out_scale=0.5, tile=tile, split_k=split_k)
+    torch.cuda.synchronize()
+    ref32 = 0.5 * (a.float() @ w.float().t()) + bias
+    _check(out32, ref32, 2e-5 * math.sqrt(k), "linear f32 out")
+
+
+def test_gemm_identity_asymmetric(eng):
+    """A = I with an asymmetric W catches transposed / permuted fragment layouts exactly."""
+    k = n = 128
+    a = torch.eye(k, device=DEV).to(eng.tdt)
+    w = (torch.arange(n * k, device=DEV).reshape(n, k) % 251).float().to(eng.tdt)
+    out = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, k, 1, 1, out_f32=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, w.float().t().contiguous())
+
+
+def test_gemm_geglu(eng):
+    m, c = 200, 128
+    a = _rand((m, c), 5).to(eng.tdt)
+    w = _rand((8 * c, c), 6, c ** -0.5)
+    bias = _rand((8 * c,), 7)
+    perm = eng._geglu_perm(8 * c).to(DEV)
+    wp = eng._pack_mat(w, geglu=True)
+    assert torch.equal(wp, w.to(eng.tdt)[perm])
+    proj = a.float() @ w.to(eng.tdt).float().t() + bias
+    val, gate = proj.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    out = eng.gemm([(a, c, 1, 1, 1, 0)], wp, 8 * c, m, 1, 1, bias=bias[perm].contiguous(), geglu=True)
+    torch.cuda.synchronize()
+    assert out.shape == (m, 4 * c)
+    _check(out, ref, _tol(eng), "geglu")
+
+
+@pytest.mark.parametrize("b,h,w_,cin,cout,stride,up,tile", [
+    (2, 16, 16, 64, 128, 1, 0, 0), (1, 8, 8, 128, 64, 1, 0, 4), (2, 16, 16, 64, 64, 2, 0, 0),
+    (1, 8, 8, 128, 128, 1, 1, 0), (2, 13, 11, 64, 320, 1, 0, 1), (1, 32, 32, 320, 320, 1, 0, 0), (3, 8, 8, 192, 4, 1, 0, 0)])
+def test_gemm_conv3x3(eng, b, h, w_, cin, cout, stride, up, tile):
+    x = _rand((b, cin, h, w_), 10).to(eng.tdt)
+    w = _rand((cout, cin, 3, 3), 11, (9 * cin) ** -0.5)
+    bias = _rand((cout,), 12)
+    sb = _rand((b, cout), 13)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xin, w.to(eng.tdt).float(), bias, stride=stride, padding=1) + sb[:, :, None, None]
+    oh, ow = ref.shape[2], ref.shape[3]
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    wp = eng._pack_conv(w)
+    out = eng.gemm([(x_nhwc, cin, 9, h, w_, up)], wp, cout, b, oh, ow, bias=bias, sbias=(sb, 0, cout), stride=stride, tile=tile)
+    torch.cuda.synchronize()
+    _check(out.view(b, oh, ow, cout).permute(0, 3, 1, 2), ref, _tol(eng), "conv3x3")
+
+
+def test_gemm_concat_shortcut(eng):
+    """conv2(3x3 over n2) + 1x1 shortcut over cat([xa, xb]) fused as K segments."""
+    b, h, w_, ca, cb, cout = 2, 8, 8, 128, 64, 128
+    n2 = _rand((b, cout, h, w_), 20).to(eng.tdt)
+    xa = _rand((b, ca, h, w_), 21).to(eng.tdt)
+    xb = _rand((b, cb, h, w_), 22).to(eng.tdt)
+    w2 = _rand((cout, cout, 3, 3), 23, (9 * cout) ** -0.5)
+    ws = _rand((cout, ca + cb, 1, 1), 24, (ca + cb) ** -0.5)
+    bias = _rand((cout,), 25)
+    ref = F.conv2d(n2.float(), w2.to(eng.tdt).float(), None, padding=1) + \
+        F.conv2d(torch.cat([xa, xb], 1).float(), ws.to(eng.tdt).float(), bias)
+    wf = torch.cat([eng._pack_conv(w2), eng._pack_mat(ws.reshape(cout, ca + cb))], dim=1).contiguous()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    out = eng.gemm([(nhwc(n2), cout, 9, h, w_, 0), (nhwc(xa), ca, 1, h, w_, 0), (nhwc(xb), cb, 1, h, w_, 0)], wf, cout, b, h, w_,
+                   bias=bias)
+    torch.cuda.synchronize()
+    _check(out.view(b, h, w_, cout).permute(0, 3, 1, 2), ref, _tol(eng), "concat+shortcut")
+    for sk in (2, 5):
+        out = eng.gemm([(nhwc(n2), cout, 9, h, w_, 0), (nhwc(xa), ca, 1, h, w_, 0), (nhwc(xb), cb, 1, h, w_, 0)], wf, cout, b,
+                       h, w_, bias=bias, split_k=sk)
+        torch.cuda.synchronize()
+        _check(out.view(b, h, w_, cout).permute(0, 3, 1, 2), ref, _tol(eng), f"concat+shortcut splitk={sk}")
+
+
+def test_gemm_rejects_bad_args(eng):
+    from faceposegenerator_amd._lib import IdbError
+    a = _rand((64, 100), 1).to(eng.tdt)
+    w = _rand((64, 100), 2).to(eng.tdt)
+    with pytest.raises(IdbError):
+        eng.gemm([(a, 100, 1, 1, 1, 0)], w, 64, 64, 1, 1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# norms / softmax
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,hw,c0,c1,silu,eps", [(2, 256, 64, 0, True, 1e-5), (3, 64, 320, 0, False, 1e-6), (2, 100, 1280, 640, True, 1e-5),
+                                                 (1, 4096, 128, 0, True, 1e-6), (2, 64, 1280, 1280, True, 1e-5), (4, 1024, 640, 320, True, 1e-5)])
+def test_groupnorm(eng, b, hw, c0, c1, silu, eps):
+    x0 = (_rand((b, hw, c0), 30) * 2 + 0.5).to(eng.tdt)
+    x1 = (_rand((b, hw, c1), 31) - 1.0).to(eng.tdt) if c1 else None
+    c = c0 + c1
+    gamma, beta = _rand((c,), 32) * 0.2 + 1, _rand((c,), 33) * 0.1
+    xcat = torch.cat([x0, x1], -1) if c1 else x0
+    ref = F.group_norm(xcat.float().permute(0, 2, 1), 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    out = eng.groupnorm(x0, c0, x1, c1, b, hw, gamma, beta, eps, silu, groups=32)
+    torch.cuda.synchronize()
+    _check(out.view(b, hw, c).permute(0, 2, 1), ref, _tol(eng), "groupnorm")
+
+
+@pytest.mark.parametrize("rows,c", [(1000, 320), (77, 640), (513, 1280), (64, 64)])
+def test_layernorm(eng, rows, c):
+    x = (_rand((rows, c), 40) * 3 + 1).to(eng.tdt)
+    gamma, beta = _rand((c,), 41) * 0.2 + 1, _rand((c,), 42) * 0.1
+    ref = F.layer_norm(x.float(), (c,), gamma, beta, 1e-5)
+    out = eng.layernorm(x, rows, c, gamma, beta)
+    torch.cuda.synchronize()
+    _check(out, ref, _tol(eng), "layernorm")
+
+
+def test_softmax_rows(eng):
+    x = (_rand((300, 4096), 50) * 4).to(eng.tdt)
+    ref = torch.softmax(x.float(), -1)
+    from faceposegenerator_amd import _lib as L
+    L.check(eng.lib.idb_softmax_rows(x.data_ptr(), 300, 4096, eng.dt, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    _check(x, ref, _tol(eng, 0.1), "softmax")
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,heads,n", [(2, 5, 1024), (1, 2, 4096), (3, 4, 64), (2, 20, 256), (1, 3, 144)])
+def test_self_attention(eng, b, heads, n):
+    c = heads * 64
+    qkv = _rand((b * n, 3 * c), 60).to(eng.tdt)
+    q, k, v = [t.float().view(b, n, heads, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b * n, c)
+    p = qkv.data_ptr()
+    out = eng.attention(qkv, 3 * c, p + 2 * c, p + 4 * c, 3 * c, b, heads, n, n, n)
+    torch.cuda.synchronize()
+    _check(out, ref, _tol(eng), "self-attention")
+
+
+def test_attention_peaked_softmax(eng):
+    """One dominant key per query (forces the online-softmax running max to jump between tiles)."""
+    b, heads, n = 1, 2, 512
+    c = heads * 64
+    g = torch.Generator().manual_seed(61)
+    q = torch.randn(b * n, c, generator=g)
+    k = torch.randn(b * n, c, generator=g)
+    idx = torch.randperm(n, generator=g)
+    k[idx] += 3.0 * q                      # key idx[i] aligned with query i -> large logit late/early in the sweep
+    v = torch.randn(b * n, c, generator=g)
+    qkv = torch.cat([q, k, v], -1).to(DEV).to(eng.tdt)
+    qq, kk, vv = [t.float().view(b, n, heads, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(b * n, c)
+    p = qkv.data_ptr()
+    out = eng.attention(qkv, 3 * c, p + 2 * c, p + 4 * c, 3 * c, b, heads, n, n, n)
+    torch.cuda.synchronize()
+    _check(out, ref, _tol(eng), "peaked attention")
+
+
+@pytest.mark.parametrize("b,heads,n,n_ctx", [(2, 5, 1024, 77), (2, 20, 64, 77), (1, 10, 256, 64), (1, 1, 128, 130)])
+def test_cross_attention(eng, b, heads, n, n_ctx):
+    c = heads * 64
+    qm = _rand((b * n, c), 70).to(eng.tdt)
+    kv = _rand((b * n_ctx, 2 * c), 71).to(eng.tdt)
+    q = qm.float().view(b, n, heads, 64).transpose(1, 2)
+    k, v = [t.float().view(b, n_ctx, heads, 64).transpose(1, 2) for t in kv.chunk(2, dim=-1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b * n, c)
+    p = kv.data_ptr()
+    out = eng.attention(qm, c, p, p + 2 * c, 2 * c, b, heads, n, n_ctx, n_ctx)
+    torch.cuda.synchronize()
+    _check(out, ref, _tol(eng), "cross-attention")
+
+
+# ---------------------------------------------------------------------------------------------------
+# small fp32 kernels
+# ---------------------------------------------------------------------------------------------------
+def test_time_embedding_path(eng):
+    from faceposegenerator_amd import _lib as L
+    from oracle import sd21_oracle as O
+    st = torch.cuda.current_stream().cuda_stream
+    ts = torch.tensor([958.0, 925.0, 34.0, 1.0, 0.0], device=DEV)
+    out = torch.empty((5, 320), device=DEV)
+    L.check(eng.lib.idb_timestep_sinusoid(ts.data_ptr(), out.data_ptr(), 5, 320, st))
+    ref = O.timestep_embedding(ts.cpu(), 320)
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() < 2e-4           # fp32 sin/cos of arguments up to ~1e3
+    x, w, b = _rand((30, 320), 80), _rand((1280, 320), 81, 320 ** -0.5), _rand((1280,), 82)
+    y = torch.empty((30, 1280), device=DEV)
+    for silu in (0, 1):
+        L.check(eng.lib.idb_linear_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 30, 1280, 320, silu, st))
+        torch.cuda.synchronize()
+        ref = F.linear(F.silu(x) if silu else x, w, b)
+        assert (y - ref).abs().max().item() < 1e-4
+
+
+def test_conv_in(eng):
+    from faceposegenerator_amd import _lib as L
+    b, h, w_, cout = 2, 16, 16, 64
+    x = _rand((b, 4, h, w_), 90)
+    w, bias = _rand((cout, 4, 3, 3), 91, 1 / 6.0), _rand((cout,), 92)
+    pw, pb = _rand((4, 4), 93, 0.5), _rand((4,), 94)
+    out = torch.empty((2 * b * h * w_, cout), dtype=eng.tdt, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(eng.lib.idb_conv_in(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), b, 2, 4, h, w_, cout, 1.0, None, None,
+                                eng.dt, st))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w, bias, padding=1)
+    got = out.view(2, b, h, w_, cout).permute(0, 1, 4, 2, 3)
+    _check(got[0], ref, _tol(eng), "conv_in")
+    assert torch.equal(got[0], got[1])
+    L.check(eng.lib.idb_conv_in(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), b, 1, 4, h, w_, cout, 1 / 0.18215,
+                                pw.data_ptr(), pb.data_ptr(), eng.dt, st))
+    torch.cuda.synchronize()
+    ref = F.conv2d(F.conv2d(x / 0.18215, pw.view(4, 4, 1, 1), pb), w, bias, padding=1)
+    _check(out[: b * h * w_].view(b, h, w_, cout).permute(0, 3, 1, 2), ref, _tol(eng, 4.0), "conv_in + post_quant")
+
+
+def test_cfg_ddpm_step_and_scheduler(eng):
+    from faceposegenerator_amd.scheduler import DDPMScheduler
+    from oracle import sd21_oracle as O
+    sch = DDPMScheduler()
+    sch.set_timesteps(30)
+    ac, ts = O.ddpm_tables(), O.ddpm_timesteps(30)
+    assert sch.timesteps.tolist() == ts
+    b, hw = 2, 64
+    for t in (958, 496, 1):
+        eps_u, eps_c = _rand((b, 4, 8, 8), 100 + t), _rand((b, 4, 8, 8), 101 + t)
+        x, nz = _rand((b, 4, 8, 8), 102 + t), _rand((b, 4, 8, 8), 103 + t)
+        ref_prev, ref_x0 = O.ddpm_step(ac, ts, t, (eps_u + 5.0 * (eps_c - eps_u)).cpu(), x.cpu(), nz.cpu())
+        # scheduler API (no CFG)
+        out = sch.step((eps_u + 5.0 * (eps_c - eps_u)), t, x, variance_noise=nz)
+        assert (out.prev_sample.cpu() - ref_prev).abs().max().item() < 2e-5 * max(1.0, ref_prev.abs().max().item())
+        assert (out.pred_original_sample.cpu() - ref_x0).abs().max().item() < 2e-5 * max(1.0, ref_x0.abs().max().item())
+        # fused CFG form used by the sampling loop
+        from faceposegenerator_amd import _lib as L
+        eps = torch.cat([eps_u, eps_c]).permute(0, 2, 3, 1).contiguous()
+        lat = x.clone()
+        coef = torch.tensor(list(sch.step_coefficients(t)) + [5.0], device=DEV)
+        L.check(eng.lib.idb_cfg_ddpm_step(eps.data_ptr(), lat.data_ptr(), nz.data_ptr(), coef.data_ptr(), None, b, 4, hw, 1, 0,
+                                          torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert (lat.cpu() - ref_prev).abs().max().item() < 2e-5 * max(1.0, ref_prev.abs().max().item())
+
+
+def test_postprocess(eng):
+    from faceposegenerator_amd import _lib as L
+    from oracle import sd21_oracle as O
+    x = _rand((2, 16, 16, 3), 110) * 1.5
+    img = torch.empty_like(x)
+    u8 = torch.empty(x.shape, dtype=torch.uint8, device=DEV)
+    L.check(eng.lib.idb_postprocess(x.data_ptr(), img.data_ptr(), u8.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ref = O.postprocess_np(x.cpu().permute(0, 3, 1, 2))
+    assert torch.equal(img.cpu(), ref)
+    assert torch.equal(u8.cpu(), O.to_uint8(ref.clone()))
+
+
+def test_lora_merge_and_pack(eng):
+    from faceposegenerator_amd import _lib as L
+    rows, cols, r = 128, 192, 4
+    w, a, b = _rand((rows, cols), 120), _rand((r, cols), 121), _rand((rows, r), 122)
+    dst = torch.empty((rows, cols), dtype=eng.tdt, device=DEV)
+    L.check(eng.lib.idb_lora_merge(w.data_ptr(), a.data_ptr(), b.data_ptr(), dst.data_ptr(), rows, cols, r, 0.5, eng.dt,
+                                   torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ref = (w + 0.5 * b @ a)
+    assert (dst.float() - ref).abs().max().item() <= _tol(eng) * ref.abs().max().item()
+    cw = _rand((8, 64, 3, 3), 123)
+    packed = eng._pack_conv(cw)
+    torch.cuda.synchronize()
+    assert torch.equal(packed, cw.permute(0, 2, 3, 1).reshape(8, -1).to(eng.tdt))
