@@ -23,13 +23,14 @@
 
 struct GemmSrcK {
     const char* ptr;
+    unsigned bytes;   // tensor size in bytes = buffer num_records (< 2^31, checked on the host)
     int C, taps, H, W, up;
 };
 
 struct GemmParams {
     GemmSrcK src[IDB_MAX_SRC];
     int M, N, HW, OW, stride;
-    long long w_row_bytes;
+    unsigned w_row_bytes, w_bytes;
     int ktiles, kt_per_split, splitk;
     const char* w;
     const float* bias;
@@ -40,12 +41,17 @@ struct GemmParams {
     int out_ld, out_f32, geglu;
     float scale;
     float* partial;
-    const char* zero;
     int tiles_n;
 };
 
-template <typename T, int MF, int NF>
+// voffset of a lane that must read zeros: beyond num_records of every descriptor (all < 2^31), and
+// voffset + soffset cannot wrap, whichever of the two the hardware range check looks at.
+[[maybe_unused]] constexpr unsigned IDB_OOB = 0x80000000u;
+[[maybe_unused]] constexpr int IDB_RSRC_FLAGS = 0x00020000;
+
+template <typename T, int MF, int NF, int NS>
 __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
     using V8 = typename Op<T>::v8;
     constexpr int BM = 32 * MF, BN = 32 * NF, STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -67,9 +73,10 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
     const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
     const int nk = kt1 - kt0;
 
-    // ---- per-thread staging coordinates: thread loads chunk position (tid&7) of rows (tid>>3)+32i
+    // ---- per-thread staging coordinates: thread loads chunk position (tid&7) of rows (tid>>3)+32i;
+    // the 16-byte chunk it fetches is (tid&7) ^ (row&7): the swizzle lives on the source address.
     const int lrow = tid >> 3;
-    const int cg16 = ((tid & 7) ^ (lrow & 7)) * 16;   // source-side swizzle (bytes)
+    const unsigned cg16 = ((tid & 7) ^ (lrow & 7)) * 16;
     int a_b[MF], a_oy[MF], a_ox[MF];
     bool a_ok[MF];
 #pragma unroll
@@ -82,18 +89,21 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
         a_oy[i] = rem / p.OW;
         a_ox[i] = rem - a_oy[i] * p.OW;
     }
-    const char* wp[NF];
-    int winc[NF];
+    // weights: one descriptor, per-row voffset fixed for the whole K loop, K position in the SGPR soffset
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
+    unsigned w_voff[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const int n = n0 + j * 32 + lrow;
-        const bool ok = n < p.N;
-        wp[j] = ok ? p.w + (long long)n * p.w_row_bytes + (long long)kt0 * 128 + cg16 : p.zero;
-        winc[j] = ok ? 128 : 0;
+        w_voff[j] = n < p.N ? (unsigned)n * p.w_row_bytes + cg16 : IDB_OOB;
     }
+    unsigned w_soff = (unsigned)kt0 * 128u;
 
-    // ---- K-step state: source s, tap, channel offset c0
-    int s = 0, tap = 0, c0 = 0;
+    // ---- K-step state: source s, tap (0..8; a 1x1 source sits on the centre tap 4), channel offset c0.
+    // Per-row voffsets (pixel address, zero padding -> out-of-range) are recomputed only when the tap or the
+    // source changes (every C/64 K-steps); inside a tap the channel offset rides in the SGPR soffset, so a
+    // K-step costs no address VALU at all.
+    int s = 0, tap = 0, c0 = 0, cur_c = 64, tap_end = 9;
     {
         int rem = kt0;
         while (s < IDB_MAX_SRC - 1) {
@@ -103,40 +113,55 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
             ++s;
         }
         const int cs = p.src[s].C >> 6;
-        tap = rem / cs;
-        c0 = (rem - tap * cs) << 6;
-    }
-
-    auto stage = [&](int buf) {
-        char* sA = smem + buf * STAGE;
-        char* sB = sA + BM * 128;
-        const GemmSrcK S = p.src[s];
-        int dy = 0, dx = 0;
-        if (S.taps == 9) {
-            const int t3 = tap / 3;
-            dy = t3 - 1;
-            dx = tap - t3 * 3 - 1;
+        if (p.src[s].taps == 9) {
+            tap = rem / cs;
+            c0 = (rem - tap * cs) << 6;
+        } else {
+            tap = 4;
+            c0 = rem << 6;
         }
+    }
+    __amdgpu_buffer_rsrc_t rs_a = rs_w;
+    unsigned a_voff[MF];
+    bool need_retap = true;
+    auto retap = [&]() {
+        const GemmSrcK S = p.src[s];
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)S.ptr, 0, S.bytes, IDB_RSRC_FLAGS);
+        cur_c = S.C;
+        tap_end = S.taps == 9 ? 9 : 5;
+        const int t3 = tap / 3;
+        const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
         const int LH = S.H << S.up, LW = S.W << S.up;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
             const bool ok = a_ok[i] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;
-            const long long pix = ((long long)a_b[i] * S.H + (iy >> S.up)) * S.W + (ix >> S.up);
-            const char* g = ok ? S.ptr + (pix * S.C + c0) * 2 + cg16 : p.zero;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(sA + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            const int pix = (a_b[i] * S.H + (iy >> S.up)) * S.W + (ix >> S.up);
+            a_voff[i] = ok ? (unsigned)pix * (unsigned)(S.C * 2) + cg16 : IDB_OOB;
         }
+    };
+    auto stage = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + BM * 128;
+        if (need_retap) {
+            retap();
+            need_retap = false;
+        }
+        const unsigned a_soff = (unsigned)c0 * 2u;
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(wp[j]), LDS_PTR(sB + (j * 256 + wave * 64) * 16), 16, 0, 0);
-            wp[j] += winc[j];
-        }
+        for (int i = 0; i < MF; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(sA + (i * 256 + wave * 64) * 16), 16, a_voff[i], a_soff, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * 256 + wave * 64) * 16), 16, w_voff[j], w_soff, 0, 0);
+        w_soff += 128u;
         c0 += 64;
-        if (c0 == S.C) {
+        if (c0 == cur_c) {
             c0 = 0;
-            if (++tap == S.taps) {
-                tap = 0;
+            need_retap = true;
+            if (++tap == tap_end) {
                 if (s < IDB_MAX_SRC - 1) ++s;
+                tap = p.src[s].taps == 9 ? 0 : 4;
             }
         }
     };
@@ -147,14 +172,20 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) {
-        stage(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
+    // ---- NS-deep LDS ring, one barrier per K-step.  At the top of iteration `it` tiles it .. it+NS-2 are in
+    // flight; the counted vmcnt retires tile `it` (this wave's share), the barrier makes every wave's share
+    // visible AND proves that all waves are done reading tile it-1, whose buffer the next DMA overwrites.
+    constexpr int LOADS = MF + NF;
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) stage(st);
+    int cur = 0;
     for (int it = 0; it < nk; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < nk) stage(cur ^ 1);
+        if (NS > 2 && it + NS - 2 < nk)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * LOADS) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (it + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1);
         const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
         const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
 #pragma unroll
@@ -170,8 +201,7 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        cur = cur + 1 == NS ? 0 : cur + 1;
     }
 
     // ---- epilogue: lane holds out[m][n .. n+3], m = tile row (lane&15), n = 4*(lane>>4) + reg
@@ -263,6 +293,7 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
             }
         }
     }
+#endif
 }
 
 // Split-K tail: sum the fp32 slabs and apply the same epilogue (bias, per-sample bias, residual).
@@ -307,8 +338,8 @@ __global__ __launch_bounds__(256) void idb_splitk_reduce_kernel(const float* __r
 namespace {
 
 struct TileCfg { int mf, nf; };
-const TileCfg kTiles[] = {{0, 0}, {4, 5}, {4, 4}, {2, 5}, {2, 4}, {4, 1}};   // index = desc.tile
-constexpr int kNumTiles = 5;
+const TileCfg kTiles[] = {{0, 0}, {4, 5}, {4, 4}, {2, 5}, {2, 4}, {4, 1}};   // index = desc.tile % 10
+constexpr int kNumTiles = 5;   // desc.tile = id (2-stage LDS ring) or 10 + id (3-stage ring, ids 1..4)
 
 struct Plan {
     int tile, splitk, tiles_m, tiles_n, ktiles, kt_per_split, M;
@@ -342,6 +373,8 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
                         "idb_gemm: 1x1 src[%d] must match the output grid", s);
         }
         K += (long long)S.taps * S.channels;
+        IDB_REQUIRE((long long)d->batch * S.in_h * S.in_w * S.channels * 2 < (1LL << 31),
+                    "idb_gemm: src[%d] tensor is >= 2 GiB; split the batch", s);
     }
     IDB_REQUIRE(d->w && idb_aligned16(d->w) && d->out && idb_aligned16(d->out), "idb_gemm: w/out null or unaligned");
     IDB_REQUIRE(d->out_ld >= (d->geglu ? d->n / 2 : d->n), "idb_gemm: out_ld too small");
@@ -353,21 +386,25 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     if (d->n % 4 == 0) IDB_REQUIRE(d->out_ld % 4 == 0, "idb_gemm: out_ld must be a multiple of 4 when n is");
     if (d->sample_bias) IDB_REQUIRE(d->sample_bias_ld == 0 || d->sample_bias_ld >= d->n, "idb_gemm: sample_bias_ld must be 0 (broadcast) or >= n");
 
+    IDB_REQUIRE((long long)d->n * K * 2 < (1LL << 31), "idb_gemm: weight matrix is >= 2 GiB");
     pl->M = (int)M;
     pl->K = K;
     pl->ktiles = (int)(K / 64);
-    int tile = d->tile;
-    IDB_REQUIRE(tile >= 0 && tile <= kNumTiles, "idb_gemm: tile id out of range");
+    int tile = d->tile % 10, ring3 = d->tile / 10;
+    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 1 && !(ring3 && (tile == 0 || tile == 5)), "idb_gemm: tile id out of range");
     if (tile == 0) {
         const bool n160 = (d->n % 160 == 0) && !d->geglu;
         const int bn = d->n <= 32 ? 32 : (n160 ? 160 : 128);
         const long long blocks_big = ((M + 127) / 128) * ((d->n + bn - 1) / bn);
+        // measured on MI355X (tools/bench_kernels.py): weight-bound layers (M <= 1024) want 128-row tiles (each
+        // weight tile is streamed by fewer workgroups) plus split-K; mid-size M wants 64-row tiles so that every CU
+        // gets at least two workgroups; large M runs fastest on the 128-row tiles.
         if (d->n <= 32) tile = 5;
-        else if (blocks_big >= 200 || M > 4096) tile = n160 ? 1 : 2;
+        else if (M <= 1024 || blocks_big >= 512) tile = n160 ? 1 : 2;
         else tile = n160 ? 3 : 4;
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
-    pl->tile = tile;
+    pl->tile = tile + 10 * ring3;
     const int bm = 32 * kTiles[tile].mf, bn = 32 * kTiles[tile].nf;
     pl->tiles_m = (int)((M + bm - 1) / bm);
     pl->tiles_n = (d->n + bn - 1) / bn;
@@ -391,13 +428,13 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     return IDB_OK;
 }
 
-template <typename T, int MF, int NF>
+template <typename T, int MF, int NF, int NS>
 int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
-    constexpr int LDS = (32 * MF + 32 * NF) * 128 * 2;
+    constexpr int LDS = (32 * MF + 32 * NF) * 128 * NS;
     static bool attr_done = false;
-    auto kern = idb_gemm_kernel<T, MF, NF>;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_gemm_kernel<T, MF, NF, NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             idb_set_error("idb_gemm: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
             return IDB_EHIP;
@@ -405,7 +442,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.splitk);
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, p);
+    hipLaunchKernelGGL((idb_gemm_kernel<T, MF, NF, NS>), grid, dim3(256), LDS, st, p);
     IDB_CHECK_LAUNCH("idb_gemm");
     return IDB_OK;
 }
@@ -414,11 +451,15 @@ template <typename T>
 int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
     int rc;
     switch (pl.tile) {
-        case 1: rc = launch_tile<T, 4, 5>(p, pl, st); break;
-        case 2: rc = launch_tile<T, 4, 4>(p, pl, st); break;
-        case 3: rc = launch_tile<T, 2, 5>(p, pl, st); break;
-        case 4: rc = launch_tile<T, 2, 4>(p, pl, st); break;
-        default: rc = launch_tile<T, 4, 1>(p, pl, st); break;
+        case 1: rc = launch_tile<T, 4, 5, 2>(p, pl, st); break;
+        case 2: rc = launch_tile<T, 4, 4, 2>(p, pl, st); break;
+        case 3: rc = launch_tile<T, 2, 5, 2>(p, pl, st); break;
+        case 4: rc = launch_tile<T, 2, 4, 2>(p, pl, st); break;
+        case 11: rc = launch_tile<T, 4, 5, 3>(p, pl, st); break;
+        case 12: rc = launch_tile<T, 4, 4, 3>(p, pl, st); break;
+        case 13: rc = launch_tile<T, 2, 5, 3>(p, pl, st); break;
+        case 14: rc = launch_tile<T, 2, 4, 3>(p, pl, st); break;
+        default: rc = launch_tile<T, 4, 1, 2>(p, pl, st); break;
     }
     if (rc != IDB_OK || pl.splitk == 1) return rc;
     const int vec = (d->n % 4 == 0) ? 4 : 1;
@@ -462,14 +503,16 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     GemmParams p = {};
     for (int s = 0; s < IDB_MAX_SRC; ++s) {
         const idb_gemm_src& S = d->src[s < d->nsrc ? s : d->nsrc - 1];
-        p.src[s] = GemmSrcK{(const char*)S.ptr, S.channels, S.taps, S.in_h, S.in_w, S.upsample};
+        p.src[s] = GemmSrcK{(const char*)S.ptr, (unsigned)((long long)d->batch * S.in_h * S.in_w * S.channels * 2), S.channels,
+                            S.taps, S.in_h, S.in_w, S.upsample};
     }
     p.M = pl.M;
     p.N = d->n;
     p.HW = d->out_h * d->out_w;
     p.OW = d->out_w;
     p.stride = d->stride;
-    p.w_row_bytes = pl.K * 2;
+    p.w_row_bytes = (unsigned)(pl.K * 2);
+    p.w_bytes = (unsigned)((long long)d->n * pl.K * 2);
     p.ktiles = pl.ktiles;
     p.kt_per_split = pl.kt_per_split;
     p.splitk = pl.splitk;
@@ -484,9 +527,8 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.geglu = d->geglu;
     p.scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     p.partial = (float*)workspace;
-    p.zero = (const char*)idb_zero_page();
     p.tiles_n = pl.tiles_n;
-    IDB_REQUIRE(p.zero != nullptr, "idb_gemm: zero page allocation failed");
     hipStream_t st = (hipStream_t)stream;
     return d->dtype == IDB_BF16 ? launch_all<__bf16>(d, p, pl, st) : launch_all<_Float16>(d, p, pl, st);
 }
+

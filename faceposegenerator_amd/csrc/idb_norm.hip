@@ -9,152 +9,173 @@
 namespace {
 
 constexpr int GN_THREADS = 256;
-constexpr int GN_MAXCOLS = 2;      // chunk columns per thread: C <= 2 * 256 * 8 = 4096 channels
+constexpr int GN_GSLOT = 4;        // groups one 8-channel chunk can touch (cpg >= 2)
+constexpr int GN_MAXCHUNKS = 64;
 
-__host__ __device__ inline int gn_nchunks(int batch, int hw) {
-    int per = 2048 / (batch > 0 ? batch : 1);
-    if (per < 1) per = 1;
-    int byhw = (hw + 63) / 64;
-    if (byhw < 1) byhw = 1;
-    int n = per < byhw ? per : byhw;
-    return n > 64 ? 64 : n;
-}
-
+// Geometry shared by the two passes.  Channels are cut into slices of SW channels (a multiple of both the
+// group width and the 8-channel vector), so a workgroup owns whole groups: grid = (pixel chunks, slices, B).
 struct GnGeom {
-    int C, C0, C1, Ct, TPR, PR, HW, groups, cpg, nchunks;
+    int C, C0, C1, HW, groups, cpg;
+    int SW, cols, PR, nslices, gps, nchunks, chunk_len;
 };
 
+inline int gn_gcd(int a, int b) { return b ? gn_gcd(b, a % b) : a; }
+
+inline GnGeom gn_geometry(int c0, int c1, int batch, int hw, int groups) {
+    GnGeom g;
+    g.C0 = c0; g.C1 = c1; g.C = c0 + c1; g.HW = hw; g.groups = groups; g.cpg = g.C / groups;
+    int sw = g.cpg / gn_gcd(g.cpg, 8) * 8;                       // lcm(cpg, 8)
+    while (sw / 8 < 8 && g.C % (sw * 2) == 0) sw *= 2;            // at least 8 vector columns when possible
+    g.SW = sw; g.cols = sw / 8; g.PR = GN_THREADS / g.cols; g.nslices = g.C / sw; g.gps = sw / g.cpg;
+    // enough pixel chunks that the grid has >= ~1024 workgroups, each with >= 2 pixels per thread row
+    int want = (1024 + batch * g.nslices - 1) / (batch * g.nslices);
+    int by_hw = (hw + 2 * g.PR - 1) / (2 * g.PR);
+    int n = want < by_hw ? want : by_hw;
+    if (n < 1) n = 1;
+    if (n > GN_MAXCHUNKS) n = GN_MAXCHUNKS;
+    g.nchunks = n;
+    g.chunk_len = (hw + n - 1) / n;
+    return g;
+}
+
 template <typename T>
-__device__ __forceinline__ void gn_load8(const T* x0, const T* x1, const GnGeom& g, long long pix, int cc, float* v) {
+__device__ __forceinline__ void gn_load8(const T* x0, const T* x1, const GnGeom& g, long long pix, int c, float* v) {
     typename Op<T>::v8 raw;
-    const int c = cc * 8;
     if (c < g.C0) raw = *(const typename Op<T>::v8*)(x0 + pix * g.C0 + c);
     else raw = *(const typename Op<T>::v8*)(x1 + pix * g.C1 + (c - g.C0));
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = to_f32<T>(raw[e]);
 }
 
-// pass 1: per (sample, pixel-chunk) partial {sum, sumsq} per group
+// pass 1: partial {sum, sumsq} per (sample, pixel chunk, group); deterministic (fixed-order LDS + shuffle trees)
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* x0, const T* x1, GnGeom g, float* partial) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = (float*)smem_raw;            // [PR][C] sums then [PR][C] sumsq
-    const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
-    const int tc = tid % g.TPR, tr = tid / g.TPR;
-    const int len = (g.HW + g.nchunks - 1) / g.nchunks;
-    const int p0 = chunk * len, p1 = min(p0 + len, g.HW);
-    float s[GN_MAXCOLS][8], ss[GN_MAXCOLS][8];
+    __shared__ float part[GN_THREADS][GN_GSLOT][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, slice = blockIdx.y, b = blockIdx.z;
+    const int col = tid % g.cols, row = tid / g.cols;
+    const int c = slice * g.SW + col * 8;                 // first channel of this thread's vector
+    const int p0 = chunk * g.chunk_len, p1 = min(p0 + g.chunk_len, g.HW);
+    float s[8], ss[8];
 #pragma unroll
-    for (int k = 0; k < GN_MAXCOLS; ++k)
+    for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    if (row < g.PR) {
+        for (int p = p0 + row; p < p1; p += g.PR) {
+            float v[8];
+            gn_load8<T>(x0, x1, g, (long long)b * g.HW + p, c, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[k][e] = ss[k][e] = 0.f;
-    if (tr < g.PR) {
-        for (int p = p0 + tr; p < p1; p += g.PR) {
-            const long long pix = (long long)b * g.HW + p;
-#pragma unroll
-            for (int k = 0; k < GN_MAXCOLS; ++k) {
-                const int cc = tc + k * g.TPR;
-                if (cc < g.Ct) {
-                    float v[8];
-                    gn_load8<T>(x0, x1, g, pix, cc, v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        s[k][e] += v[e];
-                        ss[k][e] += v[e] * v[e];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < GN_MAXCOLS; ++k) {
-            const int cc = tc + k * g.TPR;
-            if (cc < g.Ct) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    red[tr * g.C + cc * 8 + e] = s[k][e];
-                    red[(g.PR + tr) * g.C + cc * 8 + e] = ss[k][e];
-                }
+            for (int e = 0; e < 8; ++e) {
+                s[e] += v[e];
+                ss[e] += v[e] * v[e];
             }
         }
     }
-    __syncthreads();
-    for (int grp = tid; grp < g.groups; grp += GN_THREADS) {
-        float a = 0.f, q = 0.f;
-        for (int r = 0; r < g.PR; ++r)
-            for (int c = grp * g.cpg; c < (grp + 1) * g.cpg; ++c) {
-                a += red[r * g.C + c];
-                q += red[(g.PR + r) * g.C + c];
+    // fold the 8 channels into the (<= GN_GSLOT) groups they belong to
+    const int g_first = c / g.cpg;
+    float gs[GN_GSLOT], gq[GN_GSLOT];
+#pragma unroll
+    for (int k = 0; k < GN_GSLOT; ++k) gs[k] = gq[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = (c + e) / g.cpg - g_first;
+#pragma unroll
+        for (int kk = 0; kk < GN_GSLOT; ++kk)
+            if (kk == k) {
+                gs[kk] += s[e];
+                gq[kk] += ss[e];
             }
-        float* dst = partial + (((long long)b * g.nchunks + chunk) * g.groups + grp) * 2;
-        dst[0] = a;
-        dst[1] = q;
+    }
+#pragma unroll
+    for (int k = 0; k < GN_GSLOT; ++k) {
+        part[tid][k][0] = gs[k];
+        part[tid][k][1] = gq[k];
+    }
+    __syncthreads();
+    const int nact = g.cols * g.PR;
+    const int slice_g0 = slice * g.gps;
+    for (int gl = wave; gl < g.gps; gl += GN_THREADS / 64) {
+        const int ga = slice_g0 + gl;
+        float a = 0.f, q = 0.f;
+        for (int t = lane; t < nact; t += 64) {
+            const int tc = slice * g.SW + (t % g.cols) * 8;
+            const int k = ga - tc / g.cpg;
+            if (k >= 0 && k < GN_GSLOT) {
+                a += part[t][k][0];
+                q += part[t][k][1];
+            }
+        }
+        a = wave_sum(a);
+        q = wave_sum(q);
+        if (lane == 0) {
+            float* dst = partial + (((long long)b * g.nchunks + chunk) * g.groups + ga) * 2;
+            dst[0] = a;
+            dst[1] = q;
+        }
     }
 }
 
-// pass 2: y = (x - mean) * rstd * gamma + beta  [-> SiLU]
+// pass 2: y = (x - mean) * rstd * gamma + beta  [-> SiLU]; grid = (pixel blocks, slices, B)
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* x0, const T* x1, GnGeom g, const float* partial,
                                                               const float* gamma, const float* beta, float eps, int silu,
                                                               T* out, int pix_per_block) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sc = (float*)smem_raw;             // [C] scale, [C] shift, [groups] mean, [groups] rstd
-    float* sh = sc + g.C;
-    float* gm = sh + g.C;
-    float* gr = gm + g.groups;
-    const int tid = threadIdx.x, b = blockIdx.y;
-    for (int grp = tid; grp < g.groups; grp += GN_THREADS) {
-        double a = 0.0, q = 0.0;
-        for (int ch = 0; ch < g.nchunks; ++ch) {
-            const float* src = partial + (((long long)b * g.nchunks + ch) * g.groups + grp) * 2;
-            a += (double)src[0];
-            q += (double)src[1];
-        }
-        const double cnt = (double)g.HW * g.cpg;
-        const double mean = a / cnt;
-        double var = q / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        gm[grp] = (float)mean;
-        gr[grp] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
-    for (int c = tid; c < g.C; c += GN_THREADS) {
-        const int grp = c / g.cpg;
-        const float k = gr[grp] * gamma[c];
-        sc[c] = k;
-        sh[c] = beta[c] - gm[grp] * k;
-    }
-    __syncthreads();
-    const int tc = tid % g.TPR, tr = tid / g.TPR;
-    if (tr >= g.PR) return;
-    const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, g.HW);
-    float ks[GN_MAXCOLS][8], kh[GN_MAXCOLS][8];
-#pragma unroll
-    for (int k = 0; k < GN_MAXCOLS; ++k) {
-        const int cc = tc + k * g.TPR;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            ks[k][e] = cc < g.Ct ? sc[cc * 8 + e] : 0.f;
-            kh[k][e] = cc < g.Ct ? sh[cc * 8 + e] : 0.f;
-        }
-    }
-    for (int p = p0 + tr; p < p1; p += g.PR) {
-        const long long pix = (long long)b * g.HW + p;
-#pragma unroll
-        for (int k = 0; k < GN_MAXCOLS; ++k) {
-            const int cc = tc + k * g.TPR;
-            if (cc < g.Ct) {
-                float v[8];
-                gn_load8<T>(x0, x1, g, pix, cc, v);
-                typename Op<T>::v8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float y = v[e] * ks[k][e] + kh[k][e];
-                    if (silu) y = silu_f(y);
-                    o[e] = from_f32<T>(y);
+    __shared__ float gmean[64], grstd[64];
+    const int tid = threadIdx.x;
+    const int slice = blockIdx.y, b = blockIdx.z;
+    // group statistics of this slice: 8 lanes per group sum the pixel-chunk partials, then a shuffle tree
+    {
+        const int gl = tid >> 3, sub = tid & 7;
+        for (int g0 = 0; g0 < g.gps; g0 += GN_THREADS / 8) {
+            const int gi = g0 + gl;
+            float a = 0.f, q = 0.f;
+            if (gi < g.gps) {
+                const int ga = slice * g.gps + gi;
+                for (int ch = sub; ch < g.nchunks; ch += 8) {
+                    const float* src = partial + (((long long)b * g.nchunks + ch) * g.groups + ga) * 2;
+                    a += src[0];
+                    q += src[1];
                 }
-                *(typename Op<T>::v8*)(out + pix * g.C + cc * 8) = o;
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if (gi < g.gps && sub == 0) {
+                const double cnt = (double)g.HW * g.cpg;
+                const double mean = (double)a / cnt;
+                double var = (double)q / cnt - mean * mean;
+                if (var < 0.0) var = 0.0;
+                gmean[gi] = (float)mean;
+                grstd[gi] = (float)(1.0 / sqrt(var + (double)eps));
             }
         }
+    }
+    __syncthreads();
+    const int col = tid % g.cols, row = tid / g.cols;
+    if (row >= g.PR) return;
+    const int c = slice * g.SW + col * 8;
+    float ks[8], kh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int gi = (c + e) / g.cpg - slice * g.gps;
+        const float k = grstd[gi] * gamma[c + e];
+        ks[e] = k;
+        kh[e] = beta[c + e] - gmean[gi] * k;
+    }
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, g.HW);
+    for (int p = p0 + row; p < p1; p += g.PR) {
+        const long long pix = (long long)b * g.HW + p;
+        float v[8];
+        gn_load8<T>(x0, x1, g, pix, c, v);
+        typename Op<T>::v8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = v[e] * ks[e] + kh[e];
+            if (silu) y = silu_f(y);
+            o[e] = from_f32<T>(y);
+        }
+        *(typename Op<T>::v8*)(out + pix * g.C + c) = o;
     }
 }
 
@@ -252,29 +273,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int cols) {
 template <typename T>
 int run_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
                   const float* gamma, const float* beta, int silu, void* out, void* ws, hipStream_t st) {
-    GnGeom g;
-    g.C0 = c0;
-    g.C1 = c1;
-    g.C = c0 + c1;
-    g.Ct = g.C / 8;
-    g.TPR = g.Ct < GN_THREADS ? g.Ct : GN_THREADS;
-    g.PR = GN_THREADS / g.TPR;
-    g.HW = hw;
-    g.groups = groups;
-    g.cpg = g.C / groups;
-    g.nchunks = gn_nchunks(batch, hw);
-    const size_t lds1 = (size_t)2 * g.PR * g.C * sizeof(float);
-    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(g.nchunks, batch), dim3(GN_THREADS), lds1, st, (const T*)x0,
+    const GnGeom g = gn_geometry(c0, c1, batch, hw, groups);
+    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(g.nchunks, g.nslices, batch), dim3(GN_THREADS), 0, st, (const T*)x0,
                        (const T*)x1, g, (float*)ws);
     IDB_CHECK_LAUNCH("idb_groupnorm(stats)");
-    int target_blocks = 2048 / batch;
-    if (target_blocks < 1) target_blocks = 1;
-    int ppb = (hw + target_blocks - 1) / target_blocks;
-    if (ppb < g.PR * 4) ppb = g.PR * 4;
+    int want = (2048 + batch * g.nslices - 1) / (batch * g.nslices);
+    int ppb = (hw + want - 1) / want;
+    if (ppb < g.PR * 2) ppb = g.PR * 2;
     const int nblk = (hw + ppb - 1) / ppb;
-    const size_t lds2 = (size_t)(2 * g.C + 2 * groups) * sizeof(float);
-    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, batch), dim3(GN_THREADS), lds2, st, (const T*)x0, (const T*)x1,
-                       g, (const float*)ws, gamma, beta, eps, silu, (T*)out, ppb);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, g.nslices, batch), dim3(GN_THREADS), 0, st, (const T*)x0,
+                       (const T*)x1, g, (const float*)ws, gamma, beta, eps, silu, (T*)out, ppb);
     IDB_CHECK_LAUNCH("idb_groupnorm(apply)");
     return IDB_OK;
 }
@@ -283,7 +291,7 @@ int run_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int
 
 extern "C" size_t idb_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups) {
     if (batch <= 0 || hw <= 0 || groups <= 0) return 0;
-    return (size_t)batch * gn_nchunks(batch, hw) * groups * 2 * sizeof(float);
+    return (size_t)batch * GN_MAXCHUNKS * groups * 2 * sizeof(float);
 }
 
 extern "C" int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw,
@@ -296,9 +304,12 @@ extern "C" int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t
     IDB_REQUIRE(c1 == 0 || idb_aligned16(x1), "idb_groupnorm: x1 unaligned");
     const int C = c0 + c1;
     IDB_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0 && C % groups == 0, "idb_groupnorm: channels %d+%d / groups %d unsupported", c0, c1, groups);
-    IDB_REQUIRE(C / 8 <= GN_MAXCOLS * GN_THREADS, "idb_groupnorm: too many channels (%d)", C);
-    IDB_REQUIRE((size_t)(2 * (GN_THREADS / (C / 8 < GN_THREADS ? C / 8 : GN_THREADS)) * C) * 4 <= 64 * 1024,
-                "idb_groupnorm: LDS budget exceeded for C=%d", C);
+    IDB_REQUIRE(C / groups >= 2, "idb_groupnorm: needs at least 2 channels per group");
+    {
+        const GnGeom g = gn_geometry(c0, c1, batch, hw, groups);
+        IDB_REQUIRE(g.cols <= GN_THREADS && g.gps <= 64 && batch <= 65535 && g.nslices <= 65535,
+                    "idb_groupnorm: unsupported geometry C=%d groups=%d (slice %d channels, %d groups/slice)", C, groups, g.SW, g.gps);
+    }
     const size_t need = idb_groupnorm_workspace_bytes(batch, hw, groups);
     IDB_REQUIRE(workspace && workspace_bytes >= need, "idb_groupnorm: workspace too small (%zu < %zu)", workspace_bytes, need);
     hipStream_t st = (hipStream_t)stream;

@@ -114,6 +114,7 @@ class HipEngine:
         self.tproj_off: Dict[str, int] = {}
         self.tproj_total = 0
         self._pinned: set = set()
+        self.launch_log: Optional[list] = None
         self.lora_loaded = False
         if unet_sd is not None:
             self._pack_unet(unet_sd)
@@ -340,7 +341,19 @@ class HipEngine:
         d.split_k, d.tile, d.out_scale = split_k, tile, out_scale
         need = self.lib.idb_gemm_workspace_bytes(C.byref(d))
         ws = self._workspace(need) if need else None
+        log = self.launch_log
+        if log is not None:                      # bench.py's per-kernel roofline accounting (eager pass only)
+            tile, sk, blocks = C.c_int32(), C.c_int32(), C.c_int32()
+            L.check(self.lib.idb_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk), C.byref(blocks)), "idb_gemm_plan")
+            k_total = sum(ch * taps for (_, ch, taps, _, _, _) in srcs)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         L.check(self.lib.idb_gemm(C.byref(d), _ptr(ws), need, _stream()), "idb_gemm")
+        if log is not None:
+            ev1.record()
+            log.append({"tile": tile.value, "split_k": sk.value, "blocks": blocks.value, "m": m, "n": n, "k": k_total,
+                        "flops": 2.0 * m * n * k_total, "ev": (ev0, ev1),
+                        "bytes": 2.0 * (m * k_total / (9 if srcs[0][2] == 9 else 1) + n * k_total + m * ncols)})
         return out
 
     def linear(self, x: torch.Tensor, w: torch.Tensor, n: int, k: int, **kw) -> torch.Tensor:

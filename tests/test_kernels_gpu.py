@@ -44,7 +44,9 @@ def _check(out, ref, tol, what=""):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k,tile,split_k", [
     (256, 320, 320, 1, 1), (300, 128, 64, 2, 1), (128, 160, 1280, 3, 4), (77, 256, 1024, 4, 3),
-    (1000, 4, 576, 5, 1), (64, 3, 128, 5, 2), (512, 640, 2560, 0, 0), (4096, 960, 320, 0, 0), (130, 1280, 1280, 0, 0)])
+    (1000, 4, 576, 5, 1), (64, 3, 128, 5, 2), (512, 640, 2560, 0, 0), (4096, 960, 320, 0, 0), (130, 1280, 1280, 0, 0),
+    (256, 320, 320, 11, 1), (300, 128, 64, 12, 1), (128, 160, 1280, 13, 4), (77, 256, 1024, 14, 3), (700, 640, 128, 11, 1),
+    (512, 384, 192, 12, 2)])
 def test_gemm_linear(eng, m, n, k, tile, split_k):
     a = _rand((m, k), 1).to(eng.tdt)
     w = _rand((n, k), 2, k ** -0.5).to(eng.tdt)
@@ -89,7 +91,9 @@ def test_gemm_geglu(eng):
 
 @pytest.mark.parametrize("b,h,w_,cin,cout,stride,up,tile", [
     (2, 16, 16, 64, 128, 1, 0, 0), (1, 8, 8, 128, 64, 1, 0, 4), (2, 16, 16, 64, 64, 2, 0, 0),
-    (1, 8, 8, 128, 128, 1, 1, 0), (2, 13, 11, 64, 320, 1, 0, 1), (1, 32, 32, 320, 320, 1, 0, 0), (3, 8, 8, 192, 4, 1, 0, 0)])
+    (1, 8, 8, 128, 128, 1, 1, 0), (2, 13, 11, 64, 320, 1, 0, 1), (1, 32, 32, 320, 320, 1, 0, 0), (3, 8, 8, 192, 4, 1, 0, 0),
+    (2, 16, 16, 64, 128, 1, 0, 12), (2, 16, 16, 64, 64, 2, 0, 14), (1, 8, 8, 128, 128, 1, 1, 13), (2, 13, 11, 64, 320, 1, 0, 11),
+    (1, 6, 10, 128, 160, 1, 1, 11), (2, 9, 7, 64, 128, 2, 0, 12)])
 def test_gemm_conv3x3(eng, b, h, w_, cin, cout, stride, up, tile):
     x = _rand((b, cin, h, w_), 10).to(eng.tdt)
     w = _rand((cout, cin, 3, 3), 11, (9 * cin) ** -0.5)
@@ -122,11 +126,11 @@ def test_gemm_concat_shortcut(eng):
                    bias=bias)
     torch.cuda.synchronize()
     _check(out.view(b, h, w_, cout).permute(0, 3, 1, 2), ref, _tol(eng), "concat+shortcut")
-    for sk in (2, 5):
+    for sk, tile in ((2, 0), (5, 0), (1, 12), (3, 14), (7, 12)):
         out = eng.gemm([(nhwc(n2), cout, 9, h, w_, 0), (nhwc(xa), ca, 1, h, w_, 0), (nhwc(xb), cb, 1, h, w_, 0)], wf, cout, b,
-                       h, w_, bias=bias, split_k=sk)
+                       h, w_, bias=bias, split_k=sk, tile=tile)
         torch.cuda.synchronize()
-        _check(out.view(b, h, w_, cout).permute(0, 3, 1, 2), ref, _tol(eng), f"concat+shortcut splitk={sk}")
+        _check(out.view(b, h, w_, cout).permute(0, 3, 1, 2), ref, _tol(eng), f"concat+shortcut splitk={sk} tile={tile}")
 
 
 def test_gemm_rejects_bad_args(eng):
@@ -172,7 +176,7 @@ def test_softmax_rows(eng):
     from faceposegenerator_amd import _lib as L
     L.check(eng.lib.idb_softmax_rows(x.data_ptr(), 300, 4096, eng.dt, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
-    _check(x, ref, _tol(eng, 0.1), "softmax")
+    _check(x, ref, _tol(eng, 0.5), "softmax")      # output values up to ~1 rounded once to the operand dtype
 
 
 # ---------------------------------------------------------------------------------------------------
