@@ -95,6 +95,17 @@ def kernel_roofline(eng, batch, lat_side, n_ctx):
         a["flops"] += e["flops"]
         a["ms"] += e["ev"][0].elapsed_time(e["ev"][1])
         a["n"] += 1
+    if os.environ.get("IDB_DUMP_GEMM"):
+        shapes = {}
+        for e in log:
+            k = (e["m"], e["n"], e["k"], e["tile"], e["split_k"], e["blocks"])
+            a = shapes.setdefault(k, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e["ev"][0].elapsed_time(e["ev"][1])
+            a[2] += e["flops"]
+        for k, a in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            print(f"  gemm m={k[0]:7d} n={k[1]:5d} k={k[2]:6d} tile={k[3]:2d} splitk={k[4]:2d} blocks={k[5]:5d} x{a[0]:3d} "
+                  f"total {a[1]:8.3f} ms  {a[2] / (a[1] * 1e-3) / 1e12:7.1f} TF/s", file=sys.stderr)
     dom = max(agg, key=lambda t: agg[t]["ms"])
     a = agg[dom]
     achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12

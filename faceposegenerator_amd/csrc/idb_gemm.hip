@@ -84,10 +84,15 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
         const int m = m0 + i * 32 + lrow;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
-        a_b[i] = mm / p.HW;
-        const int rem = mm - a_b[i] * p.HW;
-        a_oy[i] = rem / p.OW;
-        a_ox[i] = rem - a_oy[i] * p.OW;
+        if (p.HW == 1) {                     // plain [M][K] matrix: no pixel decode (two integer divisions per row)
+            a_b[i] = mm;
+            a_oy[i] = a_ox[i] = 0;
+        } else {
+            a_b[i] = mm / p.HW;
+            const int rem = mm - a_b[i] * p.HW;
+            a_oy[i] = rem / p.OW;
+            a_ox[i] = rem - a_oy[i] * p.OW;
+        }
     }
     // weights: one descriptor, per-row voffset fixed for the whole K loop, K position in the SGPR soffset
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
@@ -396,11 +401,11 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         const bool n160 = (d->n % 160 == 0) && !d->geglu;
         const int bn = d->n <= 32 ? 32 : (n160 ? 160 : 128);
         const long long blocks_big = ((M + 127) / 128) * ((d->n + bn - 1) / bn);
-        // measured on MI355X (tools/bench_kernels.py): weight-bound layers (M <= 1024) want 128-row tiles (each
+        // measured on MI355X (tools/bench_kernels.py): weight-bound layers (M <= 2048) want 128-row tiles (each
         // weight tile is streamed by fewer workgroups) plus split-K; mid-size M wants 64-row tiles so that every CU
         // gets at least two workgroups; large M runs fastest on the 128-row tiles.
         if (d->n <= 32) tile = 5;
-        else if (M <= 1024 || blocks_big >= 512) tile = n160 ? 1 : 2;
+        else if (M <= 2048 || blocks_big >= 512) tile = n160 ? 1 : 2;
         else tile = n160 ? 3 : 4;
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
