@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures from the CPU fp32 oracle (oracle/sd21_oracle.py) with seeded synthetic
+weights.  The reference has no tests or fixtures for this path and its arithmetic (diffusers) cannot be imported
+offline, so these vectors pin the ORACLE's behaviour (and, through the GPU tests, the HIP path), not upstream's:
+parity with upstream stays "unpinned" (see the oracle header).
+
+  python tests/golden/make_golden.py [tiny] [full]
+
+tiny : reduced-width graph, B=2, 16x16 latents, 4 DDPM steps, CFG 5.0, LoRA   -> tiny_trajectory.npz  (seconds)
+full : BASELINE configs[0] = SD-2.1-base shapes, 1 prompt, 64x64 latent, 4 DDPM steps, CFG 5.0, no LoRA
+       -> sd21_config0.npz  (~1 minute on 8 cores; the 866 M-parameter weights are regenerated from the seed)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from faceposegenerator_amd import spec as S, weights as W
+from oracle import sd21_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def weight_fingerprint(sd, names):
+    return np.array([float(sd[n].double().sum()) for n in names], dtype=np.float64)
+
+
+def run(ucfg, vcfg, useed, vseed, lora_seed, batch, side, steps, gs, fp_names):
+    usd, vsd = W.synth_unet(ucfg, useed), W.synth_vae(vcfg, vseed)
+    lora_raw = W.synth_lora(ucfg, lora_seed) if lora_seed is not None else None
+    g = torch.Generator().manual_seed(2024)
+    pe = torch.randn(batch, 77, ucfg.cross_attention_dim, generator=g)
+    ne = torch.randn(batch, 77, ucfg.cross_attention_dim, generator=g)
+    noise = O.draw_noise(torch.Generator().manual_seed(0), batch, steps, (side, side))
+    trace = []
+    with torch.no_grad():
+        lat = O.sample(usd, ucfg, pe, ne, noise, steps, gs, lora=O.normalize_lora_keys(lora_raw) if lora_raw else None,
+                       trace=trace)
+        img = O.decode_to_images(vsd, vcfg, lat)
+    return {
+        "unet_fingerprint": weight_fingerprint(usd, fp_names), "vae_fingerprint": weight_fingerprint(vsd, ["decoder.conv_in.weight"]),
+        "timesteps": np.array(O.ddpm_timesteps(steps)), "guidance_scale": np.float32(gs),
+        "eps_uncond": torch.stack([t[0] for t in trace]).numpy(), "eps_cond": torch.stack([t[1] for t in trace]).numpy(),
+        "latents_per_step": torch.stack([t[2] for t in trace]).numpy(), "final_latents": lat.numpy(),
+        "image_u8": O.to_uint8(img.clone()).numpy(), "noise_first4": noise.flatten()[:4].numpy(),
+        "meta": np.array([useed, vseed, -1 if lora_seed is None else lora_seed, batch, side, steps, 2024, 0]),
+    }
+
+
+def main():
+    what = sys.argv[1:] or ["tiny", "full"]
+    fp = ["conv_in.weight", "mid_block.resnets.0.conv1.weight", "up_blocks.3.attentions.2.transformer_blocks.0.attn2.to_k.weight"]
+    if "tiny" in what:
+        d = run(S.TINY_UNET, S.TINY_VAE, 7, 8, 3, 2, 16, 4, 5.0, fp)
+        np.savez_compressed(os.path.join(HERE, "tiny_trajectory.npz"), **d)
+        print("tiny: final latents std", d["final_latents"].std())
+    if "full" in what:
+        torch.set_num_threads(os.cpu_count() or 8)
+        d = run(S.SD21_UNET, S.SD21_VAE, 1234, 1235, None, 1, 64, 4, 5.0, fp)
+        d["eps_uncond"] = d["eps_uncond"].astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, "sd21_config0.npz"), **d)
+        print("full: final latents std", d["final_latents"].std(), "image mean", d["image_u8"].mean())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,251 @@
+"""CPU tests (-m "not gpu"): the oracle against the known answers and structural invariants of SURVEY.md
+Appendix C/E/F, the committed golden vectors, and the host-side mirrors (scheduler, weights I/O, pipeline
+argument checks).  No GPU compute happens here."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from faceposegenerator_amd import spec as S, weights as W
+from faceposegenerator_amd.scheduler import DDPMScheduler
+from oracle import sd21_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- Appendix F: structural invariants --------------------------------------------------------------
+def test_published_parameter_counts():
+    assert S.count_params(S.unet_param_shapes()) == 865_910_724
+    assert S.count_params(S.vae_decoder_param_shapes()) == 49_490_199
+    lora = S.lora_param_shapes()
+    assert S.count_params(lora) == 829_952 and len(lora) == 256
+
+
+def test_algorithmic_work_matches_baseline_md():
+    assert S.unet_macs() == 402_128_732_160
+    assert S.vae_decode_macs() == 1_257_259_466_752
+    per_image = 60 * 2 * S.unet_macs() + 2 * S.vae_decode_macs()
+    assert abs(per_image / 1e12 - 50.77) < 0.01
+    assert abs(2 * S.unet_macs(latent_side=96) / 1e9 - 2149.11) < 0.5       # 768x768 config
+
+
+def test_unet_graph_shape_invariants():
+    g = S.unet_graph()
+    assert g.skip_channels == [320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280]
+    assert [64 // d for d in g.skip_side_div] == [64, 64, 64, 32, 32, 32, 16, 16, 16, 8, 8, 8]
+    resnets = [r for b in g.down + g.up for r in b["resnets"]] + g.mid["resnets"]
+    assert len(resnets) == 22 and sum(r.cin != r.cout for r in resnets) == 14
+    assert len(S.unet_attention_modules()) == 16
+    assert sum(1 for b in g.down if b["down"]) == 3 and sum(1 for b in g.up if b["up"]) == 3
+    up_in = [r.cin for b in g.up for r in b["resnets"]]
+    assert up_in == [2560, 2560, 2560, 2560, 2560, 1920, 1920, 1280, 960, 960, 640, 640]
+
+
+# ---- Appendix C: scheduler / embedding known answers -----------------------------------------------
+def test_scheduler_known_answers():
+    ac = O.ddpm_tables()
+    for idx, val in ((0, 0.99914998), (1, 0.99829602), (500, 0.27633247), (999, 0.00466010)):
+        assert abs(ac[idx].item() - val) < 5e-8
+    assert O.ddpm_timesteps(4) == [751, 501, 251, 1]
+    ts30 = O.ddpm_timesteps(30)
+    assert ts30 == [1 + 33 * k for k in range(29, -1, -1)]
+    kat4 = {751: (0.05571898, 0.44282490, 0.34559989, 0.78244293), 501: (0.27499884, 0.66816682, 0.28924572, 0.51690716),
+            251: (0.67215115, 0.99565125, 0.00426475, 0.04120697), 1: (0.99829602, 1.0, 0.0, 1.0e-10)}
+    for t, want in kat4.items():
+        got = O.ddpm_coefficients(ac, O.ddpm_timesteps(4), t)
+        assert all(abs(a - b) < 2e-7 for a, b in zip(got, want)), (t, got)
+    got = O.ddpm_coefficients(ac, ts30, 958)
+    assert all(abs(a - b) < 2e-7 for a, b in zip(got, (0.00753477, 0.03215177, 0.83015662, 0.55242407)))
+
+
+def test_sinusoid_and_rng_known_answers():
+    te = O.timestep_embedding(torch.tensor([958]), 320)[0]
+    want = [-0.98279631, 0.93290263, 0.99485564, 0.18469287, -0.36012876, 0.10130244]
+    assert all(abs(te[i].item() - w) < 2e-6 for i, w in zip([0, 1, 159, 160, 161, 319], want))
+    g = torch.Generator().manual_seed(0)
+    first = torch.randn((1, 4, 64, 64), generator=g).flatten()[:4]
+    assert torch.allclose(first, torch.tensor([-1.12583983, -1.15236020, -0.25057858, -0.43387881]), atol=1e-7)
+
+
+def test_rng_draw_order_is_latents_then_one_per_step():
+    n = O.draw_noise(torch.Generator().manual_seed(3), 2, 30, (8, 8))
+    assert n.shape == (31, 2, 4, 8, 8)
+    g = torch.Generator().manual_seed(3)
+    for i in range(31):
+        assert torch.equal(n[i], torch.randn((2, 4, 8, 8), generator=g))
+
+
+# ---- host mirror of the scheduler vs the oracle ----------------------------------------------------
+def test_host_scheduler_matches_oracle():
+    sch = DDPMScheduler()
+    assert sch.init_noise_sigma == 1.0 and sch.config.prediction_type == "epsilon" and len(sch) == 1000
+    for n in (4, 30, 50):
+        sch.set_timesteps(n)
+        assert sch.timesteps.tolist() == O.ddpm_timesteps(n)
+    sch.set_timesteps(30)
+    ac, ts = O.ddpm_tables(), O.ddpm_timesteps(30)
+    g = torch.Generator().manual_seed(1)
+    x, e, nz = (torch.randn(2, 4, 8, 8, generator=g) for _ in range(3))
+    for t in (958, 463, 1):
+        ref_prev, ref_x0 = O.ddpm_step(ac, ts, t, e, x, nz)
+        out = sch.step(e, t, x, variance_noise=nz)
+        assert torch.allclose(out.prev_sample, ref_prev, atol=2e-6, rtol=1e-6)
+        assert torch.allclose(out.pred_original_sample, ref_x0, atol=2e-5, rtol=1e-6)
+        assert sch.step(e, t, x, variance_noise=nz, return_dict=False)[0].shape == x.shape
+    # generator-driven noise: same stream as torch.randn on that generator
+    out = sch.step(e, 958, x, generator=torch.Generator().manual_seed(9))
+    ref, _ = O.ddpm_step(ac, ts, 958, e, x, torch.randn(x.shape, generator=torch.Generator().manual_seed(9)))
+    assert torch.allclose(out.prev_sample, ref, atol=2e-6)
+    # v-prediction branch (BASELINE config 5)
+    sv = DDPMScheduler(S.SchedulerConfig(prediction_type="v_prediction"))
+    sv.set_timesteps(30)
+    ref_prev, _ = O.ddpm_step(ac, ts, 463, e, x, nz, "v_prediction")
+    assert torch.allclose(sv.step(e, 463, x, variance_noise=nz).prev_sample, ref_prev, atol=2e-6)
+    # training-side helpers
+    t = torch.tensor([10, 500])
+    noisy = sch.add_noise(x, nz, t)
+    assert torch.allclose(noisy[1], ac[500] ** 0.5 * x[1] + (1 - ac[500]) ** 0.5 * nz[1])
+    vel = sch.get_velocity(x, nz, t)
+    assert torch.allclose(vel[0], ac[10] ** 0.5 * nz[0] - (1 - ac[10]) ** 0.5 * x[0])
+    with pytest.raises(ValueError):
+        DDPMScheduler(S.SchedulerConfig(beta_schedule="linear"))
+
+
+# ---- oracle self-consistency -------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny():
+    return W.synth_unet(S.TINY_UNET, 7), W.synth_vae(S.TINY_VAE, 8), W.synth_lora(S.TINY_UNET, 3)
+
+
+def test_lora_merged_equals_unmerged_and_both_dialects(tiny):
+    usd, _, lora_raw = tiny
+    g = torch.Generator().manual_seed(1)
+    x, ctx = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 77, 128, generator=g)
+    lora = O.normalize_lora_keys(lora_raw)
+    assert len(lora) == 256 and all(k.endswith((".lora_A.weight", ".lora_B.weight")) for k in lora)
+    peft = O.normalize_lora_keys(W.synth_lora(S.TINY_UNET, 3, dialect="peft"))
+    assert peft.keys() == lora.keys() and all(torch.equal(peft[k], lora[k]) for k in lora)
+    assert W.normalize_lora_keys(lora_raw).keys() == lora.keys()
+    with torch.no_grad():
+        a = O.unet_forward(usd, S.TINY_UNET, x, 500, ctx, lora)
+        b = O.unet_forward(O.merge_lora(usd, lora), S.TINY_UNET, x, 500, ctx, None)
+        c = O.unet_forward(usd, S.TINY_UNET, x, 500, ctx, None)
+    assert (a - b).abs().max() < 2e-5 and (a - c).abs().max() > 1e-3
+
+
+def test_oracle_is_deterministic_and_batch_consistent(tiny):
+    usd, _, _ = tiny
+    g = torch.Generator().manual_seed(2)
+    x, ctx = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 77, 128, generator=g)
+    with torch.no_grad():
+        a = O.unet_forward(usd, S.TINY_UNET, x, torch.tensor([900, 20]), ctx)
+        b = O.unet_forward(usd, S.TINY_UNET, x, torch.tensor([900, 20]), ctx)
+        c = O.unet_forward(usd, S.TINY_UNET, x[1:], 20, ctx[1:])
+    assert torch.equal(a, b) and (a[1:] - c).abs().max() < 1e-5
+
+
+def test_postprocess_and_uint8_quantisation():
+    x = torch.tensor([[[[-3.0, -1.0, 0.0, 0.999, 1.0, 7.0]]]])
+    img = O.postprocess_np(x)
+    assert torch.allclose(img.flatten(), torch.tensor([0.0, 0.0, 0.5, 0.9995, 1.0, 1.0]))
+    assert O.to_uint8(img.clone()).flatten().tolist() == [0, 0, 128, 255, 255, 255]
+
+
+# ---- committed golden vectors -------------------------------------------------------------------------
+def test_oracle_reproduces_tiny_golden_trajectory(tiny):
+    usd, vsd, lora_raw = tiny
+    gold = np.load(os.path.join(GOLD, "tiny_trajectory.npz"))
+    useed, vseed, lseed, batch, side, steps, eseed, nseed = gold["meta"].tolist()
+    assert (useed, vseed, lseed) == (7, 8, 3)
+    names = ["conv_in.weight", "mid_block.resnets.0.conv1.weight",
+             "up_blocks.3.attentions.2.transformer_blocks.0.attn2.to_k.weight"]
+    assert np.allclose([float(usd[n].double().sum()) for n in names], gold["unet_fingerprint"], rtol=0, atol=1e-9)
+    g = torch.Generator().manual_seed(eseed)
+    pe = torch.randn(batch, 77, 128, generator=g)
+    ne = torch.randn(batch, 77, 128, generator=g)
+    noise = O.draw_noise(torch.Generator().manual_seed(nseed), batch, steps, (side, side))
+    assert np.array_equal(noise.flatten()[:4].numpy(), gold["noise_first4"])
+    trace = []
+    with torch.no_grad():
+        lat = O.sample(usd, S.TINY_UNET, pe, ne, noise, steps, float(gold["guidance_scale"]),
+                       lora=O.normalize_lora_keys(lora_raw), trace=trace)
+        img = O.decode_to_images(vsd, S.TINY_VAE, lat)
+    assert gold["timesteps"].tolist() == [751, 501, 251, 1]
+    # same machine/torch build reproduces bit-for-bit; allow fp32 reassociation noise across CPUs
+    assert np.abs(lat.numpy() - gold["final_latents"]).max() < 5e-4
+    assert np.abs(torch.stack([t[2] for t in trace]).numpy() - gold["latents_per_step"]).max() < 5e-4
+    assert np.abs(O.to_uint8(img.clone()).numpy().astype(int) - gold["image_u8"].astype(int)).max() <= 1
+
+
+def test_full_size_golden_fixture_is_wellformed():
+    gold = np.load(os.path.join(GOLD, "sd21_config0.npz"))
+    assert gold["final_latents"].shape == (1, 4, 64, 64) and gold["latents_per_step"].shape == (4, 1, 4, 64, 64)
+    assert gold["image_u8"].shape == (1, 512, 512, 3) and gold["image_u8"].dtype == np.uint8
+    assert gold["timesteps"].tolist() == [751, 501, 251, 1]
+    assert np.isfinite(gold["final_latents"]).all() and 0.3 < gold["final_latents"].std() < 10
+
+
+# ---- weights I/O and pipeline argument checks (host logic) --------------------------------------------
+def test_model_dir_roundtrip_and_lora_files(tmp_path, tiny):
+    usd, vsd, lora_raw = tiny
+    root = str(tmp_path / "model")
+    W.save_model_dir(root, usd, vsd, S.TINY_UNET, S.TINY_VAE)
+    assert W.load_unet_config(root).block_out_channels == S.TINY_UNET.block_out_channels
+    assert W.load_unet_config(root).num_heads == S.TINY_UNET.num_heads
+    assert W.load_vae_config(root).block_out_channels == S.TINY_VAE.block_out_channels
+    assert W.load_scheduler_config(root).steps_offset == 1
+    back = W.load_unet_weights(root)
+    assert back.keys() == usd.keys() and all(torch.equal(back[k], usd[k]) for k in usd)
+    vback = W.load_vae_decoder_weights(root)
+    assert vback.keys() == vsd.keys()
+    sch = DDPMScheduler.from_pretrained(root, subfolder="scheduler")
+    sch.set_timesteps(30)
+    assert sch.timesteps[0].item() == 958
+    # LoRA checkpoint directory in the layout the reference loads (inference_ID-Booth.py:98,107)
+    ck = str(tmp_path / "Trained_LoRA_Models" / "ID-Booth" / "ID_1" / "checkpoint-31-6400")
+    W.save_lora(ck, lora_raw)
+    tensors, alphas = W.load_lora(ck)
+    assert alphas == {} and len(tensors) == 256
+    # legacy VAE attention key names (SD-2.x hub files)
+    legacy = {}
+    for k, v in vsd.items():
+        for new, old in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
+            k = k.replace(f".attentions.0.{new}.", f".attentions.0.{old}.")
+        legacy[k] = v
+    from safetensors.torch import save_file
+    save_file(legacy, os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+    assert W.load_vae_decoder_weights(root).keys() == vsd.keys()
+    with pytest.raises(FileNotFoundError):
+        W.load_unet_weights(str(tmp_path / "nope"))
+
+
+def test_pipeline_argument_checks_without_gpu(tmp_path, tiny):
+    from faceposegenerator_amd.pipeline import StableDiffusionPipeline
+    usd, vsd, _ = tiny
+    with pytest.raises(FileNotFoundError):
+        StableDiffusionPipeline.from_pretrained("stabilityai/stable-diffusion-2-1-base")
+    root = str(tmp_path / "m")
+    W.save_model_dir(root, usd, vsd, S.TINY_UNET, S.TINY_VAE)
+    pipe = StableDiffusionPipeline.from_pretrained(root, torch_dtype=torch.float16)
+    assert pipe.dtype_name == "f16" and pipe.vae.config.scaling_factor == 0.18215 and pipe.vae_scale_factor == 8
+    pipe.set_progress_bar_config(disable=True)
+    pipe.scheduler = DDPMScheduler.from_pretrained(root, subfolder="scheduler")
+    pe = torch.zeros(1, 77, 128)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 100, 128, None, pe, pe)
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", 128, 128, None, pe, None)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 128, 128, None, None, None)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 128, 128, None, pe, torch.zeros(1, 76, 128))
+    with pytest.raises(ValueError):
+        StableDiffusionPipeline(S.TINY_UNET, S.TINY_VAE, usd, vsd, torch_dtype=torch.float32)
+    with pytest.raises(FileNotFoundError):
+        pipe.load_lora_weights(str(tmp_path / "missing"))
+    n = pipe.prepare_noise(2, 3, 128, 128, torch.Generator().manual_seed(4))
+    assert n.shape == (4, 2, 4, 16, 16) and torch.equal(n, O.draw_noise(torch.Generator().manual_seed(4), 2, 3, (16, 16)))
+    with pytest.raises(ValueError):
+        pipe.prepare_noise(2, 3, 128, 128, [torch.Generator().manual_seed(1)])
