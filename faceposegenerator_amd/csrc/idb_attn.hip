@@ -16,6 +16,7 @@
 //                 ds_read_b64_tr_b16 (hardware transpose read), in the k-order the accumulator imposes.
 // LDS rows are padded (K: 144 B, V: 192 B) so ds_read_b128 / ds_read_b64_tr_b16 are conflict-free.
 #include "idb_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -24,8 +25,8 @@ constexpr int VS = 192;   // V tile row stride (bytes): (VS/4) mod 64 == 48 -> t
 constexpr int KV_TILE = 64;
 constexpr int K_BYTES = KV_TILE * KS, V_BYTES = KV_TILE * VS, BUF_BYTES = K_BYTES + V_BYTES;
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k,
+template <typename T, int NW>   // NW waves = 32*NW query rows per workgroup (4: large grids, 2: small grids)
+__global__ __launch_bounds__(64 * NW) void attn_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k,
                                                    const T* __restrict__ v, int kv_ld, T* __restrict__ out, int out_ld,
                                                    int n_q, int n_kv, int n_kv_alloc, float scale_log2e) {
     using V8 = typename Op<T>::v8;
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
 
     // ---- Q^T fragments (B operand): lane (r,h) holds Q[q0+r][16s + 8h .. +7], s = 0..3
     V8 qf[4];
@@ -50,13 +51,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
     const T* vbase = v + (long long)b * n_kv_alloc * kv_ld + head * 64;
     const int ntiles = (n_kv + KV_TILE - 1) / KV_TILE;
 
-    // staging: thread loads 16-B chunk (tid&7) of rows (tid>>3) and (tid>>3)+32 of the K and V tiles
+    // staging: thread loads 16-B chunk (tid&7) of rows (tid>>3) + 8*NW*i of the K and V tiles
+    constexpr int CH = 8 / NW, RSTEP = 8 * NW;
     const int srow = tid >> 3, schunk = tid & 7;
-    V8 kreg[2], vreg[2];
+    V8 kreg[CH], vreg[CH];
     auto gload = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = min(t * KV_TILE + srow + 32 * i, n_kv - 1);   // clamp: masked later, must stay finite
+        for (int i = 0; i < CH; ++i) {
+            const int row = min(t * KV_TILE + srow + RSTEP * i, n_kv - 1);   // clamp: masked later, must stay finite
             kreg[i] = *(const V8*)(kbase + (long long)row * kv_ld + schunk * 8);
             vreg[i] = *(const V8*)(vbase + (long long)row * kv_ld + schunk * 8);
         }
@@ -65,9 +67,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
         char* kb_ = smem + buf * BUF_BYTES;
         char* vb_ = kb_ + K_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(V8*)(kb_ + (srow + 32 * i) * KS + schunk * 16) = kreg[i];
-            *(V8*)(vb_ + (srow + 32 * i) * VS + schunk * 16) = vreg[i];
+        for (int i = 0; i < CH; ++i) {
+            *(V8*)(kb_ + (srow + RSTEP * i) * KS + schunk * 16) = kreg[i];
+            *(V8*)(vb_ + (srow + RSTEP * i) * VS + schunk * 16) = vreg[i];
         }
     };
 
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
     const int tr_row = 4 * h + ((lane & 15) >> 2);
     const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile_body = [&](auto TAIL, int t) {
         const int cur = t & 1;
         if (t + 1 < ntiles) gload(t + 1);
         const char* kt = smem + cur * BUF_BYTES;
@@ -97,33 +99,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
         f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const V8 kf = *(const V8*)(kt + (kb * 32 + r) * KS + (2 * s + h) * 16);
-                sacc[kb] = Op<T>::mfma32(kf, qf[s], sacc[kb]);
+                sacc[kb] = Op<T>::mfma32(kf, qf[s], s == 0 ? zero : sacc[kb]);     // literal-0 C operand on the first step
             }
         }
-        // scale to log2 domain, mask keys beyond n_kv (last tile only)
-        const bool tail = (t + 1) * KV_TILE > n_kv;
+        // online softmax on the RAW scores: the scale (and log2 e) rides in the exp2 argument as one FMA per element
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float sv = sacc[kb][i] * scale_log2e;
-                if (tail) {
+                if constexpr (decltype(TAIL)::value) {        // mask keys beyond n_kv (last, partial tile only)
                     const int key = t * KV_TILE + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= n_kv) sv = -INFINITY;
+                    if (key >= n_kv) sacc[kb][i] = -INFINITY;
                 }
-                sacc[kb][i] = sv;
-                mx = fmaxf(mx, sv);
+                mx = fmaxf(mx, sacc[kb][i]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+        const bool grew = m_new > m_run;
         m_run = m_new;
+        const float mb = m_new * scale_log2e;
         float rs = 0.f;
         V8 pf[2][2];
 #pragma unroll
@@ -132,15 +132,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float pv = __builtin_amdgcn_exp2f(sacc[kb][8 * s2 + j] - m_new);
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][8 * s2 + j], scale_log2e, -mb));
                     rs += pv;
                     pf[kb][s2][j] = from_f32<T>(pv);
                 }
         l_run = l_run * alpha + rs;
+        if (__builtin_amdgcn_ballot_w64(grew) != 0) {         // wave-uniform: no row max moved -> alpha == 1 everywhere
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+                for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+        }
 
         // ---- O^T[d][q] += V^T P^T
 #pragma unroll
@@ -165,7 +167,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ q, int 
 
         if (t + 1 < ntiles) lstore(cur ^ 1);
         __syncthreads();
-    }
+    };
+    const int nfull = n_kv / KV_TILE;                         // tiles without masking code at all
+    for (int t = 0; t < nfull; ++t) tile_body(std::false_type{}, t);
+    if (nfull < ntiles) tile_body(std::true_type{}, nfull);
 
     // ---- epilogue: lane (q = r, half h) holds O[q][32*d + 8*(i>>2) + 4h + (i&3)]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -197,14 +202,22 @@ extern "C" int idb_attention(const void* q, int32_t q_ld, const void* k, const v
     IDB_REQUIRE(q_ld >= heads * 64 && kv_ld >= heads * 64 && out_ld >= heads * 64, "idb_attention: row stride < heads*64");
     IDB_REQUIRE(batch <= 65535 && heads <= 65535, "idb_attention: grid too large");
     const float sl2 = scale * 1.44269504088896340736f;
-    dim3 grid((n_q + 127) / 128, heads, batch);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == IDB_BF16)
-        hipLaunchKernelGGL((attn_kernel<__bf16>), grid, dim3(256), 0, st, (const __bf16*)q, q_ld, (const __bf16*)k,
-                           (const __bf16*)v, kv_ld, (__bf16*)out, out_ld, n_q, n_kv, n_kv_alloc, sl2);
-    else
-        hipLaunchKernelGGL((attn_kernel<_Float16>), grid, dim3(256), 0, st, (const _Float16*)q, q_ld, (const _Float16*)k,
-                           (const _Float16*)v, kv_ld, (_Float16*)out, out_ld, n_q, n_kv, n_kv_alloc, sl2);
+    // 64-row blocks only when 128-row blocks would leave half the CUs idle (measured: slower otherwise)
+    const long long blocks128 = (long long)((n_q + 127) / 128) * heads * batch;
+    const bool small = blocks128 < 128;
+    const dim3 grid((n_q + (small ? 63 : 127)) / (small ? 64 : 128), heads, batch);
+#define IDB_ATTN_LAUNCH(T, NW)                                                                                          \
+    hipLaunchKernelGGL((attn_kernel<T, NW>), grid, dim3(64 * NW), 0, st, (const T*)q, q_ld, (const T*)k, (const T*)v, kv_ld, \
+                       (T*)out, out_ld, n_q, n_kv, n_kv_alloc, sl2)
+    if (dtype == IDB_BF16) {
+        if (small) IDB_ATTN_LAUNCH(__bf16, 2);
+        else IDB_ATTN_LAUNCH(__bf16, 4);
+    } else {
+        if (small) IDB_ATTN_LAUNCH(_Float16, 2);
+        else IDB_ATTN_LAUNCH(_Float16, 4);
+    }
+#undef IDB_ATTN_LAUNCH
     IDB_CHECK_LAUNCH("idb_attention");
     return IDB_OK;
 }

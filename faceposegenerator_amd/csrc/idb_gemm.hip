@@ -20,6 +20,7 @@
 //   * small-M layers (8x8 / 16x16 levels at batch 1) use split-K with fp32 slabs + a fused
 //     reduce/epilogue kernel (deterministic, no atomics).
 #include "idb_common.h"
+#include <stdlib.h>
 
 struct GemmSrcK {
     const char* ptr;
@@ -42,12 +43,219 @@ struct GemmParams {
     float scale;
     float* partial;
     int tiles_n;
+    int dbg_skip_store, lds_epi;
 };
 
 // voffset of a lane that must read zeros: beyond num_records of every descriptor (all < 2^31), and
 // voffset + soffset cannot wrap, whichever of the two the hardware range check looks at.
 [[maybe_unused]] constexpr unsigned IDB_OOB = 0x80000000u;
 [[maybe_unused]] constexpr int IDB_RSRC_FLAGS = 0x00020000;
+
+// LDS-staged epilogue (operand-dtype outputs): the accumulator tile goes through LDS so that global traffic is
+// whole 16-byte-per-lane row segments (full 128-B lines) instead of 8-byte pieces at a row stride — measured on the
+// K = C projection GEMMs, the scattered stores alone cost as much as the whole K loop.
+//   phase R (residual only): coalesced copy of the residual tile into LDS
+//   phase W: each lane adds bias / per-sample bias / residual (fp32, ONE rounding) and writes its 4-channel pieces in place
+//   phase S: coalesced LDS -> global stores
+template <typename T, int MF, int NF, bool GEGLU>
+__device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
+                                                 int wm, int wn, int fr, int fg) {
+    using V8 = typename Op<T>::v8;
+    using V4 = typename Op<T>::v4;
+    constexpr int BM = 32 * MF, BN = 32 * NF;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;          // output columns of this tile
+    constexpr int OLD = BNO * 2 + 16;                  // LDS row stride (bytes), 16-B aligned, de-phased banks
+    constexpr int CPR = BNO / 8;                       // 16-byte chunks per row
+    constexpr int ITER = BM * CPR / 256;
+    const int No = GEGLU ? p.N / 2 : p.N;
+    const int n0o = GEGLU ? n0 / 2 : n0;
+    __syncthreads();                                   // every wave is done reading the last K tile
+    if (p.res) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int q = it * 256 + tid;
+            const int row = q / CPR, c = q - row * CPR;
+            const int m = m0 + row, n = n0o + c * 8;
+            if (m < p.M && n < No)
+                *(V8*)(smem + row * OLD + c * 16) = *(const V8*)((const T*)p.res + (long long)m * p.out_ld + n);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int row = (wm * MF + i) * 16 + fr;
+        const int mc = min(m0 + row, p.M - 1);
+        const float* sb = p.sbias ? p.sbias + (long long)(mc / p.HW) * p.sbias_ld : nullptr;
+        if constexpr (GEGLU) {
+#pragma unroll
+            for (int j = 0; j < NF; j += 2) {
+                const int nv = n0 + (wn * NF + j) * 16 + fg * 4;
+                const int col = (wn * NF + j) * 8 + fg * 4;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][e] * p.scale, gt = acc[i][j + 1][e] * p.scale;
+                    if (p.bias && nv + 16 < p.N) {
+                        v += p.bias[nv + e];
+                        gt += p.bias[nv + 16 + e];
+                    }
+                    o[e] = v * gelu_erf_f(gt);
+                }
+                V4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
+                *(V4*)(smem + row * OLD + col * 2) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int col = (wn * NF + j) * 16 + fg * 4;
+                const int n = n0 + col;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
+                if (n < p.N) {
+                    if (p.bias) {
+                        const f32x4 b4 = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += b4[e];
+                    }
+                    if (sb) {
+                        const f32x4 b4 = *(const f32x4*)(sb + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += b4[e];
+                    }
+                }
+                if (p.res) {
+                    const V4 r4 = *(const V4*)(smem + row * OLD + col * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += to_f32<T>(r4[e]);
+                }
+                V4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
+                *(V4*)(smem + row * OLD + col * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int q = it * 256 + tid;
+        const int row = q / CPR, c = q - row * CPR;
+        const int m = m0 + row, n = n0o + c * 8;
+        if (m < p.M && n < No) *(V8*)((T*)p.out + (long long)m * p.out_ld + n) = *(const V8*)(smem + row * OLD + c * 16);
+    }
+}
+
+// Everything after the K loop: LDS-staged coalesced epilogue for operand-dtype outputs, direct epilogue for fp32
+// outputs / split-K slabs / odd widths.
+template <typename T, int MF, int NF>
+__device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
+                                                  int wm, int wn, int fr, int fg) {
+    if (p.dbg_skip_store) {                 // profiling experiment: keep the accumulators live, write nothing
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 123.456f) ((float*)p.out)[0] = keep;
+        return;
+    }
+    if (p.lds_epi) {
+        if (p.geglu) {
+            if constexpr ((NF & 1) == 0) idb_lds_epilogue<T, MF, NF, true>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+        } else {
+            idb_lds_epilogue<T, MF, NF, false>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+        }
+        return;
+    }
+    // ---- direct epilogue (fp32 outputs, split-K slabs, odd widths): lane holds out[m][n .. n+3], m = tile row (lane&15), n = 4*(lane>>4) + reg
+    const bool vec_ok = (p.N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + (wm * MF + i) * 16 + fr;
+        if (m >= p.M) continue;
+        if (p.splitk > 1) {
+            float* dst = p.partial + ((long long)blockIdx.z * p.M + m) * p.N;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int n = n0 + (wn * NF + j) * 16 + fg * 4;
+                if (vec_ok && n + 3 < p.N) {
+                    *(f32x4*)(dst + n) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) dst[n + e] = acc[i][j][e];
+                }
+            }
+            continue;
+        }
+        const float* sb = p.sbias ? p.sbias + (long long)(m / p.HW) * p.sbias_ld : nullptr;
+        if (p.geglu) {
+            if constexpr ((NF & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < NF; j += 2) {
+                    const int nv = n0 + (wn * NF + j) * 16 + fg * 4;   // packed row of the value part
+                    if (nv >= p.N) continue;   // N % 32 == 0: a value/gate pair is in range or not as a whole
+                    const int oc = (n0 + (wn * NF + j) * 16) / 2 + fg * 4;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][e] * p.scale, gt = acc[i][j + 1][e] * p.scale;
+                        if (p.bias) {
+                            v += p.bias[nv + e];
+                            gt += p.bias[nv + 16 + e];
+                        }
+                        o[e] = v * gelu_erf_f(gt);
+                    }
+                    T* dst = (T*)p.out + (long long)m * p.out_ld + oc;
+                    typename Op<T>::v4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
+                    *(typename Op<T>::v4*)dst = pk;
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int n = n0 + (wn * NF + j) * 16 + fg * 4;
+            if (n >= p.N) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
+            if (vec_ok && n + 3 < p.N) {
+                if (p.bias) {
+                    const f32x4 b4 = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
+                }
+                if (sb) {
+                    const f32x4 b4 = *(const f32x4*)(sb + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
+                }
+                if (p.res) {
+                    const typename Op<T>::v4 r4 = *(const typename Op<T>::v4*)((const T*)p.res + (long long)m * p.out_ld + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += to_f32<T>(r4[e]);
+                }
+                if (p.out_f32) {
+                    *(f32x4*)((float*)p.out + (long long)m * p.out_ld + n) = (f32x4){o[0], o[1], o[2], o[3]};
+                } else {
+                    typename Op<T>::v4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
+                    *(typename Op<T>::v4*)((T*)p.out + (long long)m * p.out_ld + n) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.N) break;
+                    float v = o[e];
+                    if (p.bias) v += p.bias[n + e];
+                    if (sb) v += sb[n + e];
+                    if (p.res) v += to_f32<T>(((const T*)p.res)[(long long)m * p.out_ld + n + e]);
+                    if (p.out_f32) ((float*)p.out)[(long long)m * p.out_ld + n + e] = v;
+                    else ((T*)p.out)[(long long)m * p.out_ld + n + e] = from_f32<T>(v);
+                }
+            }
+        }
+    }
+}
 
 template <typename T, int MF, int NF, int NS>
 __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
@@ -209,95 +417,168 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
 
-    // ---- epilogue: lane holds out[m][n .. n+3], m = tile row (lane&15), n = 4*(lane>>4) + reg
-    const bool vec_ok = (p.N & 3) == 0;
+    idb_gemm_epilogue<T, MF, NF>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Register-staged variant: identical tiling, addressing and epilogue, but the operands go HBM/L2 -> VGPR
+// (buffer_load_dwordx4, asynchronous until its first use) -> LDS (ds_write_b128 after the MFMAs of the current
+// tile).  Measured on MI355X: one `buffer_load ... lds` costs ~85 issue cycles, nine of them per K-step are as long
+// as the 40 MFMAs they feed and serialise with them inside a wave; a register load + ds_write_b128 pair costs ~20.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned idb_u32x4;
+
+template <typename T, int MF, int NF>
+__global__ __launch_bounds__(256) void idb_gemm_kernel_rs(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using V8 = typename Op<T>::v8;
+    constexpr int BM = 32 * MF, BN = 32 * NF, STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+    const int nk = kt1 - kt0;
+
+    // thread stages chunk (tid&7) of rows (tid>>3)+32i: global chunk c lands at LDS chunk position c ^ (row&7)
+    const int lrow = tid >> 3;
+    const unsigned c16 = (tid & 7) * 16;
+    const int lds_off = lrow * 128 + (((tid & 7) ^ (lrow & 7)) * 16);
+    int a_b[MF], a_oy[MF], a_ox[MF];
+    bool a_ok[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-        const int m = m0 + (wm * MF + i) * 16 + fr;
-        if (m >= p.M) continue;
-        if (p.splitk > 1) {
-            float* dst = p.partial + ((long long)blockIdx.z * p.M + m) * p.N;
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int n = n0 + (wn * NF + j) * 16 + fg * 4;
-                if (vec_ok && n + 3 < p.N) {
-                    *(f32x4*)(dst + n) = acc[i][j];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.N) dst[n + e] = acc[i][j][e];
-                }
-            }
-            continue;
-        }
-        const float* sb = p.sbias ? p.sbias + (long long)(m / p.HW) * p.sbias_ld : nullptr;
-        if (p.geglu) {
-            if constexpr ((NF & 1) == 0) {
-#pragma unroll
-                for (int j = 0; j < NF; j += 2) {
-                    const int nv = n0 + (wn * NF + j) * 16 + fg * 4;   // packed row of the value part
-                    if (nv >= p.N) continue;   // N % 32 == 0: a value/gate pair is in range or not as a whole
-                    const int oc = (n0 + (wn * NF + j) * 16) / 2 + fg * 4;
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][e] * p.scale, gt = acc[i][j + 1][e] * p.scale;
-                        if (p.bias) {
-                            v += p.bias[nv + e];
-                            gt += p.bias[nv + 16 + e];
-                        }
-                        o[e] = v * gelu_erf_f(gt);
-                    }
-                    T* dst = (T*)p.out + (long long)m * p.out_ld + oc;
-                    typename Op<T>::v4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
-                    *(typename Op<T>::v4*)dst = pk;
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int n = n0 + (wn * NF + j) * 16 + fg * 4;
-            if (n >= p.N) continue;
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
-            if (vec_ok && n + 3 < p.N) {
-                if (p.bias) {
-                    const f32x4 b4 = *(const f32x4*)(p.bias + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
-                }
-                if (sb) {
-                    const f32x4 b4 = *(const f32x4*)(sb + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
-                }
-                if (p.res) {
-                    const typename Op<T>::v4 r4 = *(const typename Op<T>::v4*)((const T*)p.res + (long long)m * p.out_ld + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += to_f32<T>(r4[e]);
-                }
-                if (p.out_f32) {
-                    *(f32x4*)((float*)p.out + (long long)m * p.out_ld + n) = (f32x4){o[0], o[1], o[2], o[3]};
-                } else {
-                    typename Op<T>::v4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
-                    *(typename Op<T>::v4*)((T*)p.out + (long long)m * p.out_ld + n) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (n + e >= p.N) break;
-                    float v = o[e];
-                    if (p.bias) v += p.bias[n + e];
-                    if (sb) v += sb[n + e];
-                    if (p.res) v += to_f32<T>(((const T*)p.res)[(long long)m * p.out_ld + n + e]);
-                    if (p.out_f32) ((float*)p.out)[(long long)m * p.out_ld + n + e] = v;
-                    else ((T*)p.out)[(long long)m * p.out_ld + n + e] = from_f32<T>(v);
-                }
-            }
+        const int m = m0 + i * 32 + lrow;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        if (p.HW == 1) {
+            a_b[i] = mm;
+            a_oy[i] = a_ox[i] = 0;
+        } else {
+            a_b[i] = mm / p.HW;
+            const int rem = mm - a_b[i] * p.HW;
+            a_oy[i] = rem / p.OW;
+            a_ox[i] = rem - a_oy[i] * p.OW;
         }
     }
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
+    unsigned w_voff[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int n = n0 + j * 32 + lrow;
+        w_voff[j] = n < p.N ? (unsigned)n * p.w_row_bytes + c16 : IDB_OOB;
+    }
+    unsigned w_soff = (unsigned)kt0 * 128u;
+
+    int s = 0, tap = 0, c0 = 0, cur_c = 64, tap_end = 9;
+    {
+        int rem = kt0;
+        while (s < IDB_MAX_SRC - 1) {
+            const int steps = p.src[s].taps * (p.src[s].C >> 6);
+            if (rem < steps) break;
+            rem -= steps;
+            ++s;
+        }
+        const int cs = p.src[s].C >> 6;
+        if (p.src[s].taps == 9) {
+            tap = rem / cs;
+            c0 = (rem - tap * cs) << 6;
+        } else {
+            tap = 4;
+            c0 = rem << 6;
+        }
+    }
+    __amdgpu_buffer_rsrc_t rs_a = rs_w;
+    unsigned a_voff[MF];
+    bool need_retap = true;
+    idb_u32x4 areg[MF], wreg[NF];
+    auto gload = [&]() {
+        if (need_retap) {
+            const GemmSrcK S = p.src[s];
+            rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)S.ptr, 0, S.bytes, IDB_RSRC_FLAGS);
+            cur_c = S.C;
+            tap_end = S.taps == 9 ? 9 : 5;
+            const int t3 = tap / 3;
+            const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
+            const int LH = S.H << S.up, LW = S.W << S.up;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LW;
+                const int pix = (a_b[i] * S.H + (iy >> S.up)) * S.W + (ix >> S.up);
+                a_voff[i] = ok ? (unsigned)pix * (unsigned)(S.C * 2) + c16 : IDB_OOB;
+            }
+            need_retap = false;
+        }
+        const unsigned a_soff = (unsigned)c0 * 2u;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[i], a_soff, 0);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) wreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_voff[j], w_soff, 0);
+        w_soff += 128u;
+        c0 += 64;
+        if (c0 == cur_c) {
+            c0 = 0;
+            need_retap = true;
+            if (++tap == tap_end) {
+                if (s < IDB_MAX_SRC - 1) ++s;
+                tap = p.src[s].taps == 9 ? 0 : 4;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* sA = smem + buf * STAGE + lds_off;
+        char* sB = sA + BM * 128;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) *(idb_u32x4*)(sA + i * 32 * 128) = areg[i];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) *(idb_u32x4*)(sB + j * 32 * 128) = wreg[j];
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        gload();
+        lstore(0);
+        __syncthreads();
+    }
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nk) gload();                      // next tile -> registers, in flight under the MFMAs below
+        const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
+        const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pos = ((ks * 4 + fg) ^ (fr & 7)) * 16;
+            V8 af[MF], wf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const V8*)(sA + i * 16 * 128 + pos);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *(const V8*)(sB + j * 16 * 128 + pos);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
+        }
+        if (it + 1 < nk) lstore(cur ^ 1);               // the other buffer was last read one barrier ago
+        __syncthreads();
+    }
+    idb_gemm_epilogue<T, MF, NF>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
 #endif
 }
 
@@ -395,8 +676,10 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     pl->M = (int)M;
     pl->K = K;
     pl->ktiles = (int)(K / 64);
-    int tile = d->tile % 10, ring3 = d->tile / 10;
-    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 1 && !(ring3 && (tile == 0 || tile == 5)), "idb_gemm: tile id out of range");
+    int tile = d->tile % 10, ring3 = d->tile / 10;     // ring3: 0 -> 2-stage, 1 -> 3-stage, 2 -> 4-stage LDS ring
+    // ring3: 0 -> 2-stage LDS-DMA ring, 1 -> 3-stage, 2 -> 4-stage, 3 -> register-staged double buffer
+    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 3 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5),
+                "idb_gemm: tile id out of range");
     if (tile == 0) {
         const bool n160 = (d->n % 160 == 0) && !d->geglu;
         const int bn = d->n <= 32 ? 32 : (n160 ? 160 : 128);
@@ -409,6 +692,16 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         else tile = n160 ? 3 : 4;
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
+    if (d->tile == 0 && tile != 5) {
+        // weight-bound layers stream cold weights from HBM once per launch: a deeper ring keeps more loads in flight
+        static const int env_ring = [] { const char* e = getenv("IDB_GEMM_RING_SMALL_M"); return e ? atoi(e) : 2; }();
+        static const int env_m = [] { const char* e = getenv("IDB_GEMM_RING_M"); return e ? atoi(e) : 2048; }();
+        if (M <= env_m && env_ring >= 3 && env_ring <= 4) ring3 = env_ring - 2;
+    }
+    if (d->tile == 0) {
+        static const int env_rs = [] { const char* e = getenv("IDB_GEMM_REGSTAGE"); return e ? atoi(e) : 0; }();
+        if (env_rs) ring3 = 3;
+    }
     pl->tile = tile + 10 * ring3;
     const int bm = 32 * kTiles[tile].mf, bn = 32 * kTiles[tile].nf;
     pl->tiles_m = (int)((M + bm - 1) / bm);
@@ -452,6 +745,25 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
     return IDB_OK;
 }
 
+template <typename T, int MF, int NF>
+int launch_tile_rs(const GemmParams& p, const Plan& pl, hipStream_t st) {
+    constexpr int LDS = (32 * MF + 32 * NF) * 128 * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_gemm_kernel_rs<T, MF, NF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            idb_set_error("idb_gemm: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
+            return IDB_EHIP;
+        }
+        attr_done = true;
+    }
+    dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.splitk);
+    hipLaunchKernelGGL((idb_gemm_kernel_rs<T, MF, NF>), grid, dim3(256), LDS, st, p);
+    IDB_CHECK_LAUNCH("idb_gemm(rs)");
+    return IDB_OK;
+}
+
 template <typename T>
 int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
     int rc;
@@ -464,9 +776,18 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 12: rc = launch_tile<T, 4, 4, 3>(p, pl, st); break;
         case 13: rc = launch_tile<T, 2, 5, 3>(p, pl, st); break;
         case 14: rc = launch_tile<T, 2, 4, 3>(p, pl, st); break;
+        case 31: rc = launch_tile_rs<T, 4, 5>(p, pl, st); break;
+        case 32: rc = launch_tile_rs<T, 4, 4>(p, pl, st); break;
+        case 33: rc = launch_tile_rs<T, 2, 5>(p, pl, st); break;
+        case 34: rc = launch_tile_rs<T, 2, 4>(p, pl, st); break;
+        case 35: rc = launch_tile_rs<T, 4, 1>(p, pl, st); break;
+        case 21: rc = launch_tile<T, 4, 5, 4>(p, pl, st); break;
+        case 22: rc = launch_tile<T, 4, 4, 4>(p, pl, st); break;
+        case 23: rc = launch_tile<T, 2, 5, 4>(p, pl, st); break;
+        case 24: rc = launch_tile<T, 2, 4, 4>(p, pl, st); break;
         default: rc = launch_tile<T, 4, 1, 2>(p, pl, st); break;
     }
-    if (rc != IDB_OK || pl.splitk == 1) return rc;
+    if (rc != IDB_OK || pl.splitk == 1 || (d->flags & 1)) return rc;
     const int vec = (d->n % 4 == 0) ? 4 : 1;
     const long long total = (long long)pl.M * d->n / vec;
     const int blocks = (int)((total + 255) / 256);
@@ -533,6 +854,12 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     p.partial = (float*)workspace;
     p.tiles_n = pl.tiles_n;
+    p.dbg_skip_store = (d->flags & 2) ? 1 : 0;
+    {
+        const int no = d->geglu ? d->n / 2 : d->n;
+        p.lds_epi = (!p.out_f32 && pl.splitk == 1 && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&
+                     (!d->residual || idb_aligned16(d->residual))) ? 1 : 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     return d->dtype == IDB_BF16 ? launch_all<__bf16>(d, p, pl, st) : launch_all<_Float16>(d, p, pl, st);
 }

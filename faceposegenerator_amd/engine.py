@@ -321,7 +321,7 @@ class HipEngine:
 
     def gemm(self, srcs, w: torch.Tensor, n: int, batch: int, oh: int, ow: int, bias=None, sbias=None,
              residual=None, geglu=False, stride=1, out_f32=False, out_scale=0.0, split_k=0, tile=0,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, flags: int = 0) -> torch.Tensor:
         """srcs: list of (tensor, channels, taps, in_h, in_w, upsample); sbias: (tensor, elem_offset, ld)."""
         m = batch * oh * ow
         ncols = n // 2 if geglu else n
@@ -338,7 +338,7 @@ class HipEngine:
             d.sample_bias_ld = sbias[2]
         d.residual, d.geglu = _ptr(residual), int(geglu)
         d.out, d.out_dtype, d.out_ld = out.data_ptr(), (L.IDB_F32 if out_f32 else self.dt), out.shape[-1]
-        d.split_k, d.tile, d.out_scale = split_k, tile, out_scale
+        d.split_k, d.tile, d.out_scale, d.flags = split_k, tile, out_scale, flags
         need = self.lib.idb_gemm_workspace_bytes(C.byref(d))
         ws = self._workspace(need) if need else None
         log = self.launch_log
@@ -352,7 +352,7 @@ class HipEngine:
         if log is not None:
             ev1.record()
             log.append({"tile": tile.value, "split_k": sk.value, "blocks": blocks.value, "m": m, "n": n, "k": k_total,
-                        "flops": 2.0 * m * n * k_total, "ev": (ev0, ev1),
+                        "flops": 2.0 * m * n * k_total, "ev": (ev0, ev1), "desc": d, "ws": (ws, need),
                         "bytes": 2.0 * (m * k_total / (9 if srcs[0][2] == 9 else 1) + n * k_total + m * ncols)})
         return out
 

@@ -82,6 +82,7 @@ typedef struct {
     int32_t split_k;          /* 0 = library heuristic, >=1 explicit */
     int32_t tile;             /* 0 = heuristic; else 1..5 selects a tile config (see idb_gemm_plan) */
     float out_scale;          /* multiplies the accumulator before bias (0 => 1.0) */
+    int32_t flags;            /* profiling/testing only — bit 0: skip the split-K reduce launch (`out` not written); bit 1: skip the epilogue stores; bit 2: force the direct (non-LDS-staged) epilogue */
 } idb_gemm_desc;
 
 size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);

@@ -40,15 +40,17 @@ def main():
             m = be * side * side
             fl = 2.0 * m * cout * taps * cin
             res = []
-            for tile in (1, 2, 3, 4, 11, 12, 13, 14, 0):
-                if cout % 160 and tile % 10 in (1, 3):
+            for tile in ((1, 31, 2, 32, 3, 33, 4, 34) if os.environ.get("IDB_KB_SHORT") else (1, 2, 3, 4, 11, 12, 13, 14, 0)):
+                if cout % 160 and tile < 100 and tile % 10 in (1, 3):
                     continue
+                flags = 2 if tile >= 100 else 0           # 100/101: tile 1/2 with the epilogue stores skipped
+                tl = tile - 99 if tile >= 100 else tile
                 def run():
                     eng.arena.reset()
                     if taps == 9:
-                        eng.gemm([(x, cin, 9, side, side, 0)], w, cout, be, side, side, tile=tile)
+                        eng.gemm([(x, cin, 9, side, side, 0)], w, cout, be, side, side, tile=tl, flags=flags)
                     else:
-                        eng.gemm([(x, cin, 1, 1, 1, 0)], w, cout, m, 1, 1, tile=tile)
+                        eng.gemm([(x, cin, 1, 1, 1, 0)], w, cout, m, 1, 1, tile=tl, flags=flags)
                 t = timeit(run)
                 res.append(f"t{tile}:{fl / t / 1e12:6.0f}")
             print(f"{name:26s} M={m:7d} {fl / 1e9:8.1f} GF | TF/s " + " ".join(res))
