@@ -21,7 +21,7 @@ EXPORTS = [
     "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm",
     "idb_pack_conv_weight", "idb_pack_matrix", "idb_lora_merge",
     "idb_groupnorm_workspace_bytes", "idb_groupnorm", "idb_layernorm",
-    "idb_attention", "idb_softmax_rows",
+    "idb_attention", "idb_embed_tokens", "idb_softmax_rows",
     "idb_timestep_sinusoid", "idb_linear_f32", "idb_conv_in",
     "idb_cfg_ddpm_step", "idb_postprocess",
     "idb_nhwc_to_nchw_f32", "idb_f32_nhwc_to_nchw", "idb_cast_f32",
@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("sample_bias", C.c_void_p),
                 ("sample_bias_ld", C.c_int32), ("residual", C.c_void_p), ("geglu", C.c_int32),
                 ("out", C.c_void_p), ("out_dtype", C.c_int32), ("out_ld", C.c_int32),
-                ("split_k", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float), ("flags", C.c_int32)]
+                ("split_k", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float), ("flags", C.c_int32), ("act", C.c_int32)]
 
 
 class IdbError(RuntimeError):
@@ -73,7 +73,8 @@ def load() -> C.CDLL:
         "idb_groupnorm_workspace_bytes": (sz, [i32, i32, i32]),
         "idb_groupnorm": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp, sz, vp]),
         "idb_layernorm": (C.c_int, [vp, vp, i64, i32, f32, vp, vp, i32, vp]),
-        "idb_attention": (C.c_int, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
+        "idb_attention": (C.c_int, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp]),
+        "idb_embed_tokens": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "idb_softmax_rows": (C.c_int, [vp, i64, i32, i32, vp]),
         "idb_timestep_sinusoid": (C.c_int, [vp, vp, i32, i32, vp]),
         "idb_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

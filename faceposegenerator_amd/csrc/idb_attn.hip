@@ -28,7 +28,7 @@ constexpr int K_BYTES = KV_TILE * KS, V_BYTES = KV_TILE * VS, BUF_BYTES = K_BYTE
 template <typename T, int NW>   // NW waves = 32*NW query rows per workgroup (4: large grids, 2: small grids)
 __global__ __launch_bounds__(64 * NW) void attn_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k,
                                                    const T* __restrict__ v, int kv_ld, T* __restrict__ out, int out_ld,
-                                                   int n_q, int n_kv, int n_kv_alloc, float scale_log2e) {
+                                                   int n_q, int n_kv, int n_kv_alloc, float scale_log2e, int causal) {
     using V8 = typename Op<T>::v8;
     using V4 = typename Op<T>::v4;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const T* __restrict__ q, 
             for (int i = 0; i < 16; ++i) {
                 if constexpr (decltype(TAIL)::value) {        // mask keys beyond n_kv (last, partial tile only)
                     const int key = t * KV_TILE + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= n_kv) sacc[kb][i] = -INFINITY;
+                    if (key >= n_kv || (causal && key > q0 + r)) sacc[kb][i] = -INFINITY;
                 }
                 mx = fmaxf(mx, sacc[kb][i]);
             }
@@ -168,9 +168,9 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const T* __restrict__ q, 
         if (t + 1 < ntiles) lstore(cur ^ 1);
         __syncthreads();
     };
-    const int nfull = n_kv / KV_TILE;                         // tiles without masking code at all
+    const int nfull = causal ? 0 : n_kv / KV_TILE;            // tiles without masking code at all
     for (int t = 0; t < nfull; ++t) tile_body(std::false_type{}, t);
-    if (nfull < ntiles) tile_body(std::true_type{}, nfull);
+    for (int t = nfull; t < ntiles; ++t) tile_body(std::true_type{}, t);     // partial last tile, or every tile when causal
 
     // ---- epilogue: lane (q = r, half h) holds O[q][32*d + 8*(i>>2) + 4h + (i&3)]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const T* __restrict__ q, 
 
 extern "C" int idb_attention(const void* q, int32_t q_ld, const void* k, const void* v, int32_t kv_ld, void* out,
                              int32_t out_ld, int32_t batch, int32_t heads, int32_t n_q, int32_t n_kv, int32_t n_kv_alloc,
-                             float scale, int32_t dtype, void* stream) {
+                             float scale, int32_t causal, int32_t dtype, void* stream) {
     IDB_REQUIRE(idb_is_operand_dtype(dtype), "idb_attention: dtype must be bf16/f16");
     IDB_REQUIRE(q && k && v && out, "idb_attention: null pointer");
     IDB_REQUIRE(idb_aligned16(q) && idb_aligned16(k) && idb_aligned16(v) && idb_aligned16(out), "idb_attention: unaligned pointer");
@@ -201,6 +201,7 @@ extern "C" int idb_attention(const void* q, int32_t q_ld, const void* k, const v
     IDB_REQUIRE(q_ld % 8 == 0 && kv_ld % 8 == 0 && out_ld % 4 == 0, "idb_attention: row strides must be multiples of 8 (q,kv) / 4 (out)");
     IDB_REQUIRE(q_ld >= heads * 64 && kv_ld >= heads * 64 && out_ld >= heads * 64, "idb_attention: row stride < heads*64");
     IDB_REQUIRE(batch <= 65535 && heads <= 65535, "idb_attention: grid too large");
+    IDB_REQUIRE(!causal || n_q == n_kv, "idb_attention: causal needs n_q == n_kv");
     const float sl2 = scale * 1.44269504088896340736f;
     hipStream_t st = (hipStream_t)stream;
     // 64-row blocks only when 128-row blocks would leave half the CUs idle (measured: slower otherwise)
@@ -209,7 +210,7 @@ extern "C" int idb_attention(const void* q, int32_t q_ld, const void* k, const v
     const dim3 grid((n_q + (small ? 63 : 127)) / (small ? 64 : 128), heads, batch);
 #define IDB_ATTN_LAUNCH(T, NW)                                                                                          \
     hipLaunchKernelGGL((attn_kernel<T, NW>), grid, dim3(64 * NW), 0, st, (const T*)q, q_ld, (const T*)k, (const T*)v, kv_ld, \
-                       (T*)out, out_ld, n_q, n_kv, n_kv_alloc, sl2)
+                       (T*)out, out_ld, n_q, n_kv, n_kv_alloc, sl2, causal)
     if (dtype == IDB_BF16) {
         if (small) IDB_ATTN_LAUNCH(__bf16, 2);
         else IDB_ATTN_LAUNCH(__bf16, 4);

@@ -43,7 +43,7 @@ struct GemmParams {
     float scale;
     float* partial;
     int tiles_n;
-    int dbg_skip_store, lds_epi;
+    int dbg_skip_store, lds_epi, act;
 };
 
 // voffset of a lane that must read zeros: beyond num_records of every descriptor (all < 2^31), and
@@ -123,6 +123,10 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] += b4[e];
                     }
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(o[e]);
                 }
                 if (p.res) {
                     const V4 r4 = *(const V4*)(smem + row * OLD + col * 2);
@@ -230,6 +234,10 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += b4[e];
                 }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(o[e]);
+                }
                 if (p.res) {
                     const typename Op<T>::v4 r4 = *(const typename Op<T>::v4*)((const T*)p.res + (long long)m * p.out_ld + n);
 #pragma unroll
@@ -248,6 +256,7 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
                     float v = o[e];
                     if (p.bias) v += p.bias[n + e];
                     if (sb) v += sb[n + e];
+                    if (p.act == 1) v = gelu_erf_f(v);
                     if (p.res) v += to_f32<T>(((const T*)p.res)[(long long)m * p.out_ld + n + e]);
                     if (p.out_f32) ((float*)p.out)[(long long)m * p.out_ld + n + e] = v;
                     else ((T*)p.out)[(long long)m * p.out_ld + n + e] = from_f32<T>(v);
@@ -670,6 +679,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         IDB_REQUIRE(d->out_ld % 4 == 0, "idb_gemm: GEGLU out_ld must be a multiple of 4");
     }
     if (d->n % 4 == 0) IDB_REQUIRE(d->out_ld % 4 == 0, "idb_gemm: out_ld must be a multiple of 4 when n is");
+    IDB_REQUIRE(d->act == 0 || (d->act == 1 && !d->geglu && !d->residual), "idb_gemm: act must be 0, or 1 (GELU) without GEGLU/residual");
     if (d->sample_bias) IDB_REQUIRE(d->sample_bias_ld == 0 || d->sample_bias_ld >= d->n, "idb_gemm: sample_bias_ld must be 0 (broadcast) or >= n");
 
     IDB_REQUIRE((long long)d->n * K * 2 < (1LL << 31), "idb_gemm: weight matrix is >= 2 GiB");
@@ -720,6 +730,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         }
     }
     IDB_REQUIRE(!(d->geglu && sk > 1), "idb_gemm: GEGLU does not support split-K");
+    if (d->act) sk = 1;
     if (sk > pl->ktiles) sk = pl->ktiles;
     pl->kt_per_split = (pl->ktiles + sk - 1) / sk;
     pl->splitk = (pl->ktiles + pl->kt_per_split - 1) / pl->kt_per_split;
@@ -855,6 +866,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.partial = (float*)workspace;
     p.tiles_n = pl.tiles_n;
     p.dbg_skip_store = (d->flags & 2) ? 1 : 0;
+    p.act = d->act;
     {
         const int no = d->geglu ? d->n / 2 : d->n;
         p.lds_epi = (!p.out_f32 && pl.splitk == 1 && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&

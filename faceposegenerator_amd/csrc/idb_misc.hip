@@ -253,6 +253,20 @@ __global__ __launch_bounds__(256) void lora_merge_kernel(const float* __restrict
     dst[i] = from_f32<T>(w[i] + scale * d);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ ids, const float* __restrict__ tok,
+                                                    const float* __restrict__ pos, T* __restrict__ out, int rows, int n_tokens, int dim) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per 4 output features
+    const int d4 = dim >> 2;
+    if (i >= (long long)rows * d4) return;
+    const int row = (int)(i / d4), c = (int)(i - (long long)row * d4) * 4;
+    const long long id = ids[row];
+    const f32x4 a = *(const f32x4*)(tok + id * dim + c);
+    const f32x4 b = *(const f32x4*)(pos + (long long)(row % n_tokens) * dim + c);
+    typename Op<T>::v4 o = {from_f32<T>(a[0] + b[0]), from_f32<T>(a[1] + b[1]), from_f32<T>(a[2] + b[2]), from_f32<T>(a[3] + b[3])};
+    *(typename Op<T>::v4*)(out + (long long)row * dim + c) = o;
+}
+
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -342,6 +356,20 @@ extern "C" int idb_cast_f32(const float* x, void* out, int64_t count, int32_t dt
     DISPATCH_T(dtype, hipLaunchKernelGGL((cast_kernel<__bf16>), dim3(blocks_for(count)), dim3(256), 0, st, x, (__bf16*)out, (long long)count),
                hipLaunchKernelGGL((cast_kernel<_Float16>), dim3(blocks_for(count)), dim3(256), 0, st, x, (_Float16*)out, (long long)count));
     IDB_CHECK_LAUNCH("idb_cast_f32");
+    return IDB_OK;
+}
+
+extern "C" int idb_embed_tokens(const int64_t* ids, const float* tok, const float* pos, void* out, int32_t batch, int32_t n_tokens,
+                                int32_t dim, int32_t dtype, void* stream) {
+    IDB_REQUIRE(idb_is_operand_dtype(dtype) && ids && tok && pos && out, "idb_embed_tokens: bad args");
+    IDB_REQUIRE(batch > 0 && n_tokens > 0 && dim > 0 && dim % 4 == 0 && idb_aligned16(tok) && idb_aligned16(pos) && idb_aligned16(out),
+                "idb_embed_tokens: dims/alignment");
+    const int rows = batch * n_tokens;
+    const unsigned nb = blocks_for((long long)rows * (dim / 4));
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((embed_kernel<__bf16>), dim3(nb), dim3(256), 0, st, (const long long*)ids, tok, pos, (__bf16*)out, rows, n_tokens, dim),
+               hipLaunchKernelGGL((embed_kernel<_Float16>), dim3(nb), dim3(256), 0, st, (const long long*)ids, tok, pos, (_Float16*)out, rows, n_tokens, dim));
+    IDB_CHECK_LAUNCH("idb_embed_tokens");
     return IDB_OK;
 }
 

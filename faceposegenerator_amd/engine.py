@@ -321,7 +321,7 @@ class HipEngine:
 
     def gemm(self, srcs, w: torch.Tensor, n: int, batch: int, oh: int, ow: int, bias=None, sbias=None,
              residual=None, geglu=False, stride=1, out_f32=False, out_scale=0.0, split_k=0, tile=0,
-             out: Optional[torch.Tensor] = None, flags: int = 0) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, flags: int = 0, act: int = 0) -> torch.Tensor:
         """srcs: list of (tensor, channels, taps, in_h, in_w, upsample); sbias: (tensor, elem_offset, ld)."""
         m = batch * oh * ow
         ncols = n // 2 if geglu else n
@@ -338,7 +338,7 @@ class HipEngine:
             d.sample_bias_ld = sbias[2]
         d.residual, d.geglu = _ptr(residual), int(geglu)
         d.out, d.out_dtype, d.out_ld = out.data_ptr(), (L.IDB_F32 if out_f32 else self.dt), out.shape[-1]
-        d.split_k, d.tile, d.out_scale, d.flags = split_k, tile, out_scale, flags
+        d.split_k, d.tile, d.out_scale, d.flags, d.act = split_k, tile, out_scale, flags, act
         need = self.lib.idb_gemm_workspace_bytes(C.byref(d))
         ws = self._workspace(need) if need else None
         log = self.launch_log
@@ -379,10 +379,10 @@ class HipEngine:
                                        self.dt, _stream()), "idb_layernorm")
         return out
 
-    def attention(self, q, q_ld, k_ptr, v_ptr, kv_ld, batch, heads, n_q, n_kv, n_kv_alloc) -> torch.Tensor:
+    def attention(self, q, q_ld, k_ptr, v_ptr, kv_ld, batch, heads, n_q, n_kv, n_kv_alloc, causal: bool = False) -> torch.Tensor:
         out = self.arena.alloc((batch * n_q, heads * 64), self.tdt)
         L.check(self.lib.idb_attention(q.data_ptr(), q_ld, k_ptr, v_ptr, kv_ld, out.data_ptr(), heads * 64, batch, heads,
-                                       n_q, n_kv, n_kv_alloc, 0.125, self.dt, _stream()), "idb_attention")
+                                       n_q, n_kv, n_kv_alloc, 0.125, int(causal), self.dt, _stream()), "idb_attention")
         return out
 
     def _free(self, t: Optional[torch.Tensor]) -> None:

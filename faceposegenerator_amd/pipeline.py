@@ -11,8 +11,10 @@ Reference usage reproduced (same names / kwargs / error behaviour, SURVEY.md §8
   * ``pipe.unet(x, t, ehs, return_dict=False)[0]`` (train_ID-Booth.py:1040-1046), ``pipe.vae.decode(z).sample``
     (:412), ``pipe.vae.config.scaling_factor`` (:1002).
 
-Text conditioning (CLIP tokenizer + text encoder) is the "next" row of SURVEY.md §8f: this sampler
-takes ``prompt_embeds``; string prompts need an ``encode_prompt`` callable supplied by the caller.
+Text conditioning: when the local model directory holds ``text_encoder/`` and ``tokenizer/`` the
+pipeline encodes string prompts itself — tokenisation is upstream's own host-side ``transformers.CLIPTokenizer`` (pure
+string processing, needs the vocab/merges files of the model directory), the 23-layer CLIP text model runs on the HIP
+kernels (``text_encoder.ClipTextEncoder``).  Without them pass ``prompt_embeds`` / ``negative_prompt_embeds``.
 """
 from __future__ import annotations
 
@@ -68,7 +70,8 @@ class VAEHandle:
 
 class StableDiffusionPipeline:
     def __init__(self, unet_config: S.UNetConfig, vae_config: S.VAEConfig, unet_sd, vae_sd,
-                 scheduler: Optional[DDPMScheduler] = None, torch_dtype=None, encode_prompt: Optional[Callable] = None):
+                 scheduler: Optional[DDPMScheduler] = None, torch_dtype=None, encode_prompt: Optional[Callable] = None,
+                 text_encoder=None, tokenizer=None):
         self.unet_config, self.vae_config = unet_config, vae_config
         self._unet_sd, self._vae_sd = unet_sd, vae_sd
         self.scheduler = scheduler or DDPMScheduler(S.SchedulerConfig(prediction_type=unet_config.prediction_type))
@@ -80,6 +83,9 @@ class StableDiffusionPipeline:
         self._lora = None
         self._progress = {}
         self.encode_prompt_fn = encode_prompt
+        self._text = text_encoder            # (ClipTextConfig, state dict) or None
+        self._text_eng = None
+        self.tokenizer = tokenizer
         self.use_graph = True
         self.vae_chunk = 4
         self.unet = UNetHandle(self)
@@ -96,7 +102,13 @@ class StableDiffusionPipeline:
         ucfg, vcfg = W.load_unet_config(root), W.load_vae_config(root)
         scfg = W.load_scheduler_config(root)
         ucfg = S.UNetConfig(**{**ucfg.__dict__, "prediction_type": scfg.prediction_type})
-        return cls(ucfg, vcfg, W.load_unet_weights(root), W.load_vae_decoder_weights(root), DDPMScheduler(scfg), torch_dtype)
+        text = W.load_text_encoder(root)
+        tokenizer = None
+        if text is not None and os.path.isdir(os.path.join(root, "tokenizer")):
+            from transformers import CLIPTokenizer           # host-side string -> ids, as the reference uses it
+            tokenizer = CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer"))
+        return cls(ucfg, vcfg, W.load_unet_weights(root), W.load_vae_decoder_weights(root), DDPMScheduler(scfg), torch_dtype,
+                   text_encoder=text, tokenizer=tokenizer)
 
     @classmethod
     def from_synthetic(cls, unet_config: S.UNetConfig = S.SD21_UNET, vae_config: S.VAEConfig = S.SD21_VAE,
@@ -123,6 +135,45 @@ class StableDiffusionPipeline:
             if self._lora is not None:
                 self._eng.set_lora(*self._lora)
         return self._eng
+
+    @property
+    def text_encoder(self):
+        """``pipe.text_encoder(ids)[0]`` (train_ID-Booth.py:484-489); None when the model dir has no text encoder."""
+        if self._text is None:
+            return None
+        if self._text_eng is None:
+            from .text_encoder import ClipTextEncoder
+            self._text_eng = ClipTextEncoder(self._engine(), *self._text)
+        return self._text_eng
+
+    def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance: bool = True):
+        """Upstream ``encode_prompt``: 77-token max-length padding + truncation, ``text_encoder(ids)[0]``; the
+        unconditional prompt defaults to "" (uncond embeddings come FIRST when concatenated by the sampler)."""
+        te = self.text_encoder
+        if te is None or self.tokenizer is None:
+            raise NotImplementedError(
+                "string prompts need text_encoder/ and tokenizer/ in the local model directory (or encode_prompt=callable); "
+                "otherwise pass `prompt_embeds`/`negative_prompt_embeds` (train_ID-Booth.py:1221-1224 style)")
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+        n_max = self.tokenizer.model_max_length if getattr(self.tokenizer, "model_max_length", 77) <= 77 else 77
+
+        def ids_of(texts):
+            enc = self.tokenizer(texts, padding="max_length", max_length=n_max, truncation=True, return_tensors="pt")
+            return enc.input_ids
+
+        pe = te.encode(ids_of(prompts))
+        ne = None
+        if do_classifier_free_guidance:
+            if negative_prompt is None:
+                negs = [""] * len(prompts)
+            elif isinstance(negative_prompt, str):
+                negs = [negative_prompt] * len(prompts)
+            else:
+                negs = list(negative_prompt)
+                if len(negs) != len(prompts):
+                    raise ValueError(f"`negative_prompt` has batch size {len(negs)}, but `prompt` has batch size {len(prompts)}.")
+            ne = te.encode(ids_of(negs))
+        return pe, ne
 
     def set_progress_bar_config(self, **kwargs) -> None:
         self._progress = dict(kwargs)
@@ -165,12 +216,9 @@ class StableDiffusionPipeline:
                              f"but got {tuple(prompt_embeds.shape)} != {tuple(negative_prompt_embeds.shape)}.")
 
     def _encode(self, prompt, negative_prompt, do_cfg):
-        if self.encode_prompt_fn is None:
-            raise NotImplementedError(
-                "string prompts need a text encoder: pass `prompt_embeds`/`negative_prompt_embeds` "
-                "(train_ID-Booth.py:1221-1224 style) or construct the pipeline with encode_prompt=callable "
-                "(CLIP text conditioning is the next row of the build plan, SURVEY.md §8f-1)")
-        return self.encode_prompt_fn(prompt, negative_prompt, do_cfg)
+        if self.encode_prompt_fn is not None:
+            return self.encode_prompt_fn(prompt, negative_prompt, do_cfg)
+        return self.encode_prompt(prompt, negative_prompt, do_cfg)
 
     def prepare_noise(self, batch: int, steps: int, height: int, width: int, generator) -> torch.Tensor:
         """RNG order of the upstream pipeline with a CPU generator (randn_tensor draws on the generator's

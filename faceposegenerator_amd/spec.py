@@ -422,3 +422,50 @@ def vae_decode_macs(cfg: VAEConfig = SD21_VAE, latent_side: int = 64) -> int:
             macs += blk["channels"] ** 2 * 9 * s * s
     macs += cfg.block_out_channels[0] * cfg.out_channels * 9 * s * s
     return macs
+
+
+# --------------------------------------------------------------------------------------
+# CLIP text encoder: transformers CLIPTextModel as SD-2.1-base ships it
+# (text_encoder/config.json: 23 pre-LN layers, width 1024, 16 heads, MLP 4096, exact GELU, causal mask)
+# --------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ClipTextConfig:
+    hidden_size: int = 1024
+    intermediate_size: int = 4096
+    num_hidden_layers: int = 23
+    num_attention_heads: int = 16
+    max_position_embeddings: int = 77
+    vocab_size: int = 49408
+    hidden_act: str = "gelu"
+    layer_norm_eps: float = 1e-5
+    bos_token_id: int = 49406
+    eos_token_id: int = 49407
+    pad_token_id: int = 0                 # SD-2.x tokenizer pads with id 0 ("!")
+
+
+SD21_CLIP = ClipTextConfig()
+TINY_CLIP = ClipTextConfig(hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                           vocab_size=1000, bos_token_id=998, eos_token_id=999)
+
+
+def clip_text_param_shapes(cfg: ClipTextConfig = SD21_CLIP) -> Dict[str, Shape]:
+    """Keys as transformers 4.34.1 writes them (``text_model.`` prefix)."""
+    d, f = cfg.hidden_size, cfg.intermediate_size
+    out: Dict[str, Shape] = {
+        "text_model.embeddings.token_embedding.weight": (cfg.vocab_size, d),
+        "text_model.embeddings.position_embedding.weight": (cfg.max_position_embeddings, d),
+        "text_model.final_layer_norm.weight": (d,), "text_model.final_layer_norm.bias": (d,),
+    }
+    for i in range(cfg.num_hidden_layers):
+        p = f"text_model.encoder.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            out[f"{p}.self_attn.{n}.weight"] = (d, d)
+            out[f"{p}.self_attn.{n}.bias"] = (d,)
+        for n in ("layer_norm1", "layer_norm2"):
+            out[f"{p}.{n}.weight"] = (d,)
+            out[f"{p}.{n}.bias"] = (d,)
+        out[f"{p}.mlp.fc1.weight"] = (f, d)
+        out[f"{p}.mlp.fc1.bias"] = (f,)
+        out[f"{p}.mlp.fc2.weight"] = (d, f)
+        out[f"{p}.mlp.fc2.bias"] = (d,)
+    return out

@@ -54,6 +54,17 @@ def synth_vae(cfg: S.VAEConfig = S.SD21_VAE, seed: int = 4321) -> SD:
     return synth_state_dict(S.vae_decoder_param_shapes(cfg), seed)
 
 
+def synth_clip(cfg: S.ClipTextConfig = S.SD21_CLIP, seed: int = 99) -> SD:
+    sd = synth_state_dict(S.clip_text_param_shapes(cfg), seed)
+    g = _gen(seed, 100003)
+    # embeddings are looked up, not multiplied: unit-variance rows like a trained table after scaling
+    sd["text_model.embeddings.token_embedding.weight"] = 0.5 * torch.randn(
+        sd["text_model.embeddings.token_embedding.weight"].shape, generator=g)
+    sd["text_model.embeddings.position_embedding.weight"] = 0.5 * torch.randn(
+        sd["text_model.embeddings.position_embedding.weight"].shape, generator=g)
+    return sd
+
+
 def synth_lora(cfg: S.UNetConfig = S.SD21_UNET, seed: int = 1, rank: int = 4, dialect: str = "diffusers") -> SD:
     """A ~ N(0, 1/r) (PEFT 'gaussian' init, train_ID-Booth.py:675); B ~ N(0, 0.02) so that the
     branch is non-zero.  Keys in the dialect the reference writes (train_ID-Booth.py:705)."""
@@ -189,6 +200,34 @@ def load_vae_decoder_weights(root: str) -> SD:
                 v = v[:, :, 0, 0]
         out[k] = v
     return out
+
+
+def load_text_encoder(root: str):
+    """(ClipTextConfig, state dict with ``text_model.`` keys) from <root>/text_encoder, or None if absent."""
+    d = os.path.join(root, "text_encoder")
+    if not os.path.isfile(os.path.join(d, "config.json")):
+        return None
+    c = _read_json(os.path.join(d, "config.json"))
+    if c.get("hidden_act", "gelu") not in ("gelu",):
+        raise ValueError(f"text encoder hidden_act {c.get('hidden_act')!r} is not supported (SD-2.x uses exact GELU)")
+    cfg = S.ClipTextConfig(hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
+                           num_hidden_layers=c["num_hidden_layers"], num_attention_heads=c["num_attention_heads"],
+                           max_position_embeddings=c.get("max_position_embeddings", 77), vocab_size=c["vocab_size"],
+                           layer_norm_eps=c.get("layer_norm_eps", 1e-5), bos_token_id=c.get("bos_token_id", 49406),
+                           eos_token_id=c.get("eos_token_id", 49407), pad_token_id=c.get("pad_token_id", 0) or 0)
+    raw = _load_safetensors(os.path.join(d, "model.safetensors"))
+    sd = {(k if k.startswith("text_model.") else "text_model." + k): v for k, v in raw.items()
+          if "text_projection" not in k and "position_ids" not in k}
+    return cfg, sd
+
+
+def save_text_encoder(root: str, cfg: S.ClipTextConfig, sd: SD) -> None:
+    from safetensors.torch import save_file
+    d = os.path.join(root, "text_encoder")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(dict(asdict(cfg), _class_name="CLIPTextModel", architectures=["CLIPTextModel"], projection_dim=512), f, indent=1)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(d, "model.safetensors"))
 
 
 def save_lora(path_or_dir: str, lora_sd: SD, weight_name: str = "pytorch_lora_weights.safetensors") -> str:

@@ -83,6 +83,7 @@ typedef struct {
     int32_t tile;             /* 0 = heuristic; else 1..5 selects a tile config (see idb_gemm_plan) */
     float out_scale;          /* multiplies the accumulator before bias (0 => 1.0) */
     int32_t flags;            /* profiling/testing only — bit 0: skip the split-K reduce launch (`out` not written); bit 1: skip the epilogue stores; bit 2: force the direct (non-LDS-staged) epilogue */
+    int32_t act;              /* 0 none, 1 exact GELU applied to (acc*scale + bias) (CLIP MLP fc1); not with residual/GEGLU */
 } idb_gemm_desc;
 
 size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);
@@ -125,7 +126,14 @@ int idb_layernorm(const void* x, void* out, int64_t rows, int32_t c, float eps, 
  * ------------------------------------------------------------------------------------------ */
 int idb_attention(const void* q, int32_t q_ld, const void* k, const void* v, int32_t kv_ld,
                   void* out, int32_t out_ld, int32_t batch, int32_t heads, int32_t n_q, int32_t n_kv,
-                  int32_t n_kv_alloc, float scale, int32_t dtype, void* stream);
+                  int32_t n_kv_alloc, float scale, int32_t causal, int32_t dtype, void* stream);
+/* causal != 0: query i attends keys 0..i only (CLIPTextModel's causal mask, n_q == n_kv). */
+
+/* Token + position embedding gather of CLIPTextModel: out[b][t][:] = tok[ids[b][t]][:] + pos[t][:]
+ * (fp32 tables, operand-dtype output).  ids are int64 on the device; out-of-range ids are an error the
+ * caller must exclude (checked on the host by the engine). */
+int idb_embed_tokens(const int64_t* ids, const float* tok, const float* pos, void* out, int32_t batch,
+                     int32_t n_tokens, int32_t dim, int32_t dtype, void* stream);
 /* In-place row softmax over [rows][cols] (VAE mid-block single-head attention, d = 512). */
 int idb_softmax_rows(void* x, int64_t rows, int32_t cols, int32_t dtype, void* stream);
 
