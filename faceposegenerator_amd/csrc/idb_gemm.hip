@@ -694,12 +694,13 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         const bool n160 = (d->n % 160 == 0) && !d->geglu;
         const int bn = d->n <= 32 ? 32 : (n160 ? 160 : 128);
         const long long blocks_big = ((M + 127) / 128) * ((d->n + bn - 1) / bn);
-        // measured on MI355X (tools/bench_kernels.py): weight-bound layers (M <= 2048) want 128-row tiles (each
-        // weight tile is streamed by fewer workgroups) plus split-K; mid-size M wants 64-row tiles so that every CU
-        // gets at least two workgroups; large M runs fastest on the 128-row tiles.
+        // measured on MI355X (tools/bench_kernels.py, tools/bench_small.py with HBM-cold weights inside a HIP graph):
+        //  * enough work for >= 2 workgroups per CU: 128-row tiles (highest FLOP per byte moved L2 -> LDS);
+        //  * weight-streaming layers (M <= 2048, long K): 128-row tiles + split-K, each weight tile read by few workgroups;
+        //  * everything else (the batch-1 projection GEMMs and 64x64-level convs): 64-row tiles so that all CUs get work.
         if (d->n <= 32) tile = 5;
-        else if (M <= 2048 || blocks_big >= 512) tile = n160 ? 1 : 2;
-        else tile = n160 ? 3 : 4;
+        else if (blocks_big >= 512 || (M <= 2048 && pl->ktiles >= 64)) tile = n160 ? 1 : 2;
+        else tile = (n160 && pl->ktiles >= 32) ? 3 : 4;
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
     if (d->tile == 0 && tile != 5) {
@@ -721,9 +722,9 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     int sk = d->split_k;
     if (sk <= 0) {
         sk = 1;
-        if (!d->geglu && blocks < 192 && pl->ktiles >= 16) {
+        if (!d->geglu && blocks < 192 && pl->ktiles >= 10) {
             sk = (int)((384 + blocks - 1) / blocks);
-            const int max_by_k = pl->ktiles / 8;
+            const int max_by_k = pl->ktiles / (kTiles[tile].mf == 2 ? 5 : 8);   // K-steps per split: >= 5 (64-row) / 8 (128-row)
             if (sk > max_by_k) sk = max_by_k;
             if (sk > 32) sk = 32;
             if (sk < 1) sk = 1;

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Batch-1 projection-GEMM shapes (cold weights, in a HIP graph): time per launch for each tile / split-K choice."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from faceposegenerator_amd import spec as S
+from faceposegenerator_amd.engine import HipEngine
+eng = HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, "cuda:0", "bf16")
+dev = eng.device
+shapes = [(8192, 320, 320), (8192, 960, 320), (8192, 320, 1280), (2048, 640, 640), (2048, 1920, 640), (2048, 640, 2560),
+          (512, 1280, 1280), (512, 3840, 1280), (512, 1280, 5120), (128, 1280, 1280), (128, 3840, 1280), (128, 1280, 5120)]
+for (m, n, k) in shapes:
+    nbuf = max(2, min(48, int(400e6 // (n * k * 2))))
+    ws = [(torch.randn(n, k, device=dev) * k ** -0.5).to(eng.tdt) for _ in range(nbuf)]
+    x = torch.randn(m, k, device=dev).to(eng.tdt)
+    res = torch.randn(m, n, device=dev).to(eng.tdt)
+    out = torch.empty(m, n, dtype=eng.tdt, device=dev)
+    line = []
+    for tile, sk in ((1, 1), (3, 1), (2, 1), (4, 1), (1, 2), (1, 4), (3, 2), (4, 2), (4, 4), (0, 0)):
+        if n % 160 and tile in (1, 3):
+            continue
+        if sk > 1 and k // 64 < 2 * sk:
+            continue
+        def run(i):
+            eng.gemm([(x, k, 1, 1, 1, 0)], ws[i % nbuf], n, m, 1, 1, out=out, residual=res, split_k=sk, tile=tile)
+        for i in range(nbuf): run(i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(nbuf): run(i)
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); g.replay(); e1.record(); torch.cuda.synchronize()
+        line.append(f"t{tile}s{sk}:{e0.elapsed_time(e1) / (2 * nbuf) * 1e3:5.1f}")
+    print(f"m={m:5d} n={n:5d} k={k:5d} us/launch  " + "  ".join(line), flush=True)
+    del ws
