@@ -40,7 +40,8 @@ class GemmDesc(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("sample_bias", C.c_void_p),
                 ("sample_bias_ld", C.c_int32), ("residual", C.c_void_p), ("geglu", C.c_int32),
                 ("out", C.c_void_p), ("out_dtype", C.c_int32), ("out_ld", C.c_int32),
-                ("split_k", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float), ("flags", C.c_int32), ("act", C.c_int32)]
+                ("split_k", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float), ("flags", C.c_int32), ("act", C.c_int32),
+                ("counters", C.c_void_p), ("counters_len", C.c_int32)]
 
 
 class IdbError(RuntimeError):

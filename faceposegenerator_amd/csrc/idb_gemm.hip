@@ -44,6 +44,7 @@ struct GemmParams {
     float* partial;
     int tiles_n;
     int dbg_skip_store, lds_epi, act;
+    unsigned* counters;   // non-null: in-kernel split-K reduce
 };
 
 // voffset of a lane that must read zeros: beyond num_records of every descriptor (all < 2^31), and
@@ -162,6 +163,76 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
         if (keep == 123.456f) ((float*)p.out)[0] = keep;
         return;
     }
+    if (p.splitk > 1) {
+        // ---- split-K: every workgroup stores its fp32 slab (16-B per lane)
+        const bool vec4 = (p.N & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = m0 + (wm * MF + i) * 16 + fr;
+            if (m >= p.M) continue;
+            float* dst = p.partial + ((long long)blockIdx.z * p.M + m) * p.N;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int n = n0 + (wn * NF + j) * 16 + fg * 4;
+                if (vec4 && n + 3 < p.N) {
+                    *(f32x4*)(dst + n) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) dst[n + e] = acc[i][j][e];
+                }
+            }
+        }
+        if (!p.counters) return;                      // two-launch mode: idb_splitk_reduce_kernel finishes the job
+        // ---- publish the slab (agent-scope release), draw a ticket; the last arriver of this tile reduces.
+        // Placement-independent protocol (cdna_hip_programming.md, Guideline 16 / "In-launch split-K reduction").
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = (unsigned*)smem;             // the K loop is done with LDS (barrier above)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned* cnt = p.counters + (m0 / (32 * MF)) * p.tiles_n + n0 / (32 * NF);
+            const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = t == (unsigned)p.splitk - 1u;
+            if (last) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the counter zero for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *flag = last ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool is_last = *flag != 0u;
+        __syncthreads();                              // flag consumed before the epilogue reuses LDS
+        if (!is_last) return;
+        // ---- deterministic reduction: every slab, own one included, in ascending split order (bit-identical to the
+        // two-launch path whoever arrives last)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = m0 + (wm * MF + i) * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int n = n0 + (wn * NF + j) * 16 + fg * 4;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                if (m < p.M) {
+                    for (int z = 0; z < p.splitk; ++z) {
+                        const float* src = p.partial + ((long long)z * p.M + m) * p.N + n;
+                        if (vec4 && n + 3 < p.N) {
+                            const f32x4 v = *(const f32x4*)src;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sum[e] += v[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < p.N) sum[e] += src[e];
+                        }
+                    }
+                }
+                acc[i][j] = sum;
+            }
+        }
+    }
     if (p.lds_epi) {
         if (p.geglu) {
             if constexpr ((NF & 1) == 0) idb_lds_epilogue<T, MF, NF, true>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
@@ -176,21 +247,6 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
     for (int i = 0; i < MF; ++i) {
         const int m = m0 + (wm * MF + i) * 16 + fr;
         if (m >= p.M) continue;
-        if (p.splitk > 1) {
-            float* dst = p.partial + ((long long)blockIdx.z * p.M + m) * p.N;
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int n = n0 + (wn * NF + j) * 16 + fg * 4;
-                if (vec_ok && n + 3 < p.N) {
-                    *(f32x4*)(dst + n) = acc[i][j];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.N) dst[n + e] = acc[i][j][e];
-                }
-            }
-            continue;
-        }
         const float* sb = p.sbias ? p.sbias + (long long)(m / p.HW) * p.sbias_ld : nullptr;
         if (p.geglu) {
             if constexpr ((NF & 1) == 0) {
@@ -799,7 +855,7 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 24: rc = launch_tile<T, 2, 4, 4>(p, pl, st); break;
         default: rc = launch_tile<T, 4, 1, 2>(p, pl, st); break;
     }
-    if (rc != IDB_OK || pl.splitk == 1 || (d->flags & 1)) return rc;
+    if (rc != IDB_OK || pl.splitk == 1 || (d->flags & 1) || p.counters) return rc;
     const int vec = (d->n % 4 == 0) ? 4 : 1;
     const long long total = (long long)pl.M * d->n / vec;
     const int blocks = (int)((total + 255) / 256);
@@ -870,7 +926,14 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.act = d->act;
     {
         const int no = d->geglu ? d->n / 2 : d->n;
-        p.lds_epi = (!p.out_f32 && pl.splitk == 1 && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&
+        // In-kernel split-K reduce (flags bit 4 only).  Measured on MI355X it LOSES to the separate reduce launch in the
+        // sampling loop (batch 1: 4.49 vs 5.11 images/s): every split workgroup pays an agent-scope release (buffer_wbl2
+        // of its XCD's L2) and one workgroup per tile re-reads all slabs — the "splitk-seam" price of the CDNA guide.
+        // The path is kept, tested bit-identical to the two-launch form, for shapes where a launch boundary is dearer.
+        const bool fused_reduce = pl.splitk > 1 && d->counters && (d->flags & 16) && !(d->flags & 8) && !(d->flags & 1) &&
+                                  (long long)pl.tiles_m * pl.tiles_n <= d->counters_len;
+        p.counters = fused_reduce ? d->counters : nullptr;
+        p.lds_epi = (!p.out_f32 && (pl.splitk == 1 || fused_reduce) && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&
                      (!d->residual || idb_aligned16(d->residual))) ? 1 : 0;
     }
     hipStream_t st = (hipStream_t)stream;

@@ -109,6 +109,7 @@ class HipEngine:
         self.arena = Arena(self.device)
         self._ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
         self._gn_ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self._counters = torch.zeros(1 << 16, dtype=torch.int32, device=self.device)   # split-K tickets (self-resetting)
         self.w: Dict[str, torch.Tensor] = {}
         self.master: Dict[str, torch.Tensor] = {}
         self.tproj_off: Dict[str, int] = {}
@@ -339,6 +340,7 @@ class HipEngine:
         d.residual, d.geglu = _ptr(residual), int(geglu)
         d.out, d.out_dtype, d.out_ld = out.data_ptr(), (L.IDB_F32 if out_f32 else self.dt), out.shape[-1]
         d.split_k, d.tile, d.out_scale, d.flags, d.act = split_k, tile, out_scale, flags, act
+        d.counters, d.counters_len = self._counters.data_ptr(), self._counters.numel()
         need = self.lib.idb_gemm_workspace_bytes(C.byref(d))
         ws = self._workspace(need) if need else None
         log = self.launch_log

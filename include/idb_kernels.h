@@ -82,8 +82,12 @@ typedef struct {
     int32_t split_k;          /* 0 = library heuristic, >=1 explicit */
     int32_t tile;             /* 0 = heuristic; else 1..5 selects a tile config (see idb_gemm_plan) */
     float out_scale;          /* multiplies the accumulator before bias (0 => 1.0) */
-    int32_t flags;            /* profiling/testing only — bit 0: skip the split-K reduce launch (`out` not written); bit 1: skip the epilogue stores; bit 2: force the direct (non-LDS-staged) epilogue */
+    int32_t flags;            /* profiling/testing only — bit 0: skip the split-K reduce launch (`out` not written); bit 1: skip the epilogue stores; bit 2: force the direct (non-LDS-staged) epilogue; bit 3: force the two-launch split-K reduce; bit 4: in-kernel split-K reduce (default: separate reduce launch, which measured faster) */
     int32_t act;              /* 0 none, 1 exact GELU applied to (acc*scale + bias) (CLIP MLP fc1); not with residual/GEGLU */
+    uint32_t* counters;       /* optional: >= counters_len zeroed uint32 on the device, private to the stream; used only with
+                                 flags bit 4: a split-K launch then reduces inside the GEMM (the last-arriving workgroup of a
+                                 tile sums the slabs in fixed order and runs the epilogue; counters are left zero) */
+    int32_t counters_len;
 } idb_gemm_desc;
 
 size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);

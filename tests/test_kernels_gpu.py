@@ -155,6 +155,35 @@ def test_gemm_lds_epilogue_equals_direct_epilogue(eng):
     assert torch.equal(o1, o2)
 
 
+def test_gemm_fused_splitk_reduce_is_bit_identical_and_stable(eng):
+    """In-kernel split-K reduction (agent-scope release + ticket + acquire, last arriver re-sums every slab in fixed
+    order) vs the two-launch path (flags bit 3): bit-identical, on every repetition, for bf16/fp32 outputs, residual,
+    partial tiles, many splits — with other work in flight so that arrival order varies, and with the reducer's L1/L2
+    pre-warmed on the slab addresses (the workspace is re-used across launches)."""
+    torch.manual_seed(0)
+    noise_a = torch.randn(4096, 1024, device=DEV).to(eng.tdt)
+    noise_w = torch.randn(1024, 1024, device=DEV).to(eng.tdt)
+    cases = [(512, 1280, 1280, 4, 4), (128, 1280, 5120, 1, 16), (130, 320, 2560, 3, 7), (2048, 640, 2560, 4, 3),
+             (300, 4, 1152, 5, 6), (77, 3, 640, 5, 5), (512, 1280, 11520, 1, 30), (200, 264, 1024, 2, 8)]
+    for (m, n, k, tile, sk) in cases:
+        a = _rand((m, k), 1).to(eng.tdt)
+        w = _rand((n, k), 2, k ** -0.5).to(eng.tdt)
+        bias = _rand((n,), 3)
+        res = _rand((m, n), 4).to(eng.tdt) if n % 8 == 0 else None
+        for out_f32 in ((False, True) if res is None else (False,)):
+            kw = dict(bias=bias, residual=res, tile=tile, split_k=sk, out_f32=out_f32)
+            eng.arena.reset()
+            ref = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, m, 1, 1, flags=8, **kw).clone()
+            for rep in range(12):
+                eng.arena.reset()
+                if rep % 3 == 0:      # unrelated traffic before/around the launch: uneven load, different arrival orders
+                    eng.gemm([(noise_a, 1024, 1, 1, 1, 0)], noise_w, 1024, 4096, 1, 1)
+                got = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, m, 1, 1, flags=16, **kw)      # bit 4: fused reduce at any split
+                torch.cuda.synchronize()
+                assert torch.equal(got, ref), (m, n, k, tile, sk, out_f32, rep)
+    assert int(eng._counters.abs().sum().item()) == 0          # tickets are left at zero
+
+
 def test_gemm_rejects_bad_args(eng):
     from faceposegenerator_amd._lib import IdbError
     a = _rand((64, 100), 1).to(eng.tdt)
