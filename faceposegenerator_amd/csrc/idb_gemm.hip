@@ -45,6 +45,7 @@ struct GemmParams {
     int tiles_n;
     int dbg_skip_store, lds_epi, act;
     unsigned* counters;   // non-null: in-kernel split-K reduce
+    unsigned out_bytes;   // persistent variant: size of the output tensor (buffer range check drops masked stores)
 };
 
 // voffset of a lane that must read zeros: beyond num_records of every descriptor (all < 2^31), and
@@ -647,6 +648,192 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel_rs(const GemmParams p) {
 #endif
 }
 
+// Epilogue of the persistent variant: same arithmetic as the direct epilogue, but EVERY lane issues exactly one
+// buffer_store_dwordx2 per (value) fragment — rows/columns outside the matrix get an out-of-range offset and are
+// dropped by the buffer range check — so the store count per wave is a compile-time constant and the K loop can wait
+// for the next tile's loads with a counted vmcnt while these stores are still in flight.
+template <typename T, int MF, int NF, bool GEGLU>
+__device__ __forceinline__ void idb_pl_epilogue(const GemmParams& p, f32x4 (&acc)[MF][NF], int m0, int n0, int wm, int wn, int fr, int fg) {
+    using V4 = typename Op<T>::v4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, IDB_RSRC_FLAGS);
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + (wm * MF + i) * 16 + fr;
+        const bool mok = m < p.M;
+        const int mc = mok ? m : 0;
+        const float* sb = p.sbias ? p.sbias + (long long)(mc / p.HW) * p.sbias_ld : nullptr;
+#pragma unroll
+        for (int j = 0; j < NF; j += (GEGLU ? 2 : 1)) {
+            const int n = n0 + (wn * NF + j) * 16 + fg * 4;               // packed row (value part for GEGLU)
+            const int oc = GEGLU ? (n0 + (wn * NF + j) * 16) / 2 + fg * 4 : n;
+            const bool nok = GEGLU ? (n + 16 < p.N) : (n < p.N);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
+            if constexpr (GEGLU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float gt = acc[i][j + 1][e] * p.scale;
+                    if (p.bias && nok) {
+                        o[e] += p.bias[n + e];
+                        gt += p.bias[n + 16 + e];
+                    }
+                    o[e] *= gelu_erf_f(gt);
+                }
+            } else {
+                if (nok) {
+                    if (p.bias) {
+                        const f32x4 b4 = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += b4[e];
+                    }
+                    if (sb) {
+                        const f32x4 b4 = *(const f32x4*)(sb + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += b4[e];
+                    }
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(o[e]);
+                }
+                if (p.res && mok && nok) {
+                    const V4 r4 = *(const V4*)((const T*)p.res + (long long)m * p.out_ld + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += to_f32<T>(r4[e]);
+                }
+            }
+            const V4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
+            const unsigned voff = (mok && nok) ? (unsigned)(((long long)m * p.out_ld + oc) * 2) : IDB_OOB;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, pk), rs_o, voff, 0, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent variant for plain [M][K] x [N][K]^T GEMMs with a SHORT K loop (the K = C projection layers of the
+// transformer blocks at large batch: 5-20 K-steps).  A grid of 2 workgroups per CU walks the output tiles; the
+// 2-deep LDS ring runs straight across tile boundaries, so the first K tile of output tile t+1 is already in
+// flight while tile t's accumulators go through the epilogue, and no workgroup launch / address prologue /
+// pipeline fill is paid per tile.  Same fragment layout and epilogue arithmetic as idb_gemm_kernel.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int MF, int NF>
+__global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p) {   // 2 waves/SIMD: two workgroups per CU
+#if defined(__HIP_DEVICE_COMPILE__)
+    using V8 = typename Op<T>::v8;
+    constexpr int BM = 32 * MF, BN = 32 * NF, STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * p.tiles_n;
+    const int G = gridDim.x, KT = p.ktiles;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * KT;
+
+    const int lrow = tid >> 3;
+    const unsigned cg16 = ((tid & 7) ^ (lrow & 7)) * 16;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src[0].ptr, 0, p.src[0].bytes, IDB_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
+    const unsigned a_row_bytes = (unsigned)p.src[0].C * 2u;        // A is [M][K], K = C of the single 1x1 source
+
+    // load-side cursor: output tile lt, K-step lk
+    int lt = blockIdx.x, lk = 0;
+    unsigned a_voff[MF], w_voff[NF];
+    auto set_tile = [&](int tile) {
+        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = tm * BM + i * 32 + lrow;
+            a_voff[i] = m < p.M ? (unsigned)m * a_row_bytes + cg16 : IDB_OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int n = tn * BN + j * 32 + lrow;
+            w_voff[j] = n < p.N ? (unsigned)n * p.w_row_bytes + cg16 : IDB_OOB;
+        }
+    };
+    set_tile(lt);
+    auto stage = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + BM * 128;
+        const unsigned soff = (unsigned)lk * 128u;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(sA + (i * 256 + wave * 64) * 16), 16, a_voff[i], soff, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * 256 + wave * 64) * 16), 16, w_voff[j], soff, 0, 0);
+        if (++lk == KT) {
+            lk = 0;
+            lt += G;
+            if (lt < ntiles) set_tile(lt);
+        }
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int ct = blockIdx.x, ck = 0;        // compute-side cursor
+    int stores_in_flight = 0;           // 1 / 2: the previous step ended with an epilogue that issued exactly MF*NF / MF*NF/2 stores
+    stage(0);
+    for (int st = 0; st < total; ++st) {
+        const int cur = st & 1;
+        // the next tile's loads are OLDER than the epilogue's stores: a counted wait retires the loads only
+        if (stores_in_flight == 1)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MF * NF) : "memory");
+        else if (stores_in_flight == 2)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MF * NF / 2) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        stores_in_flight = 0;
+        if (st + 1 < total) stage(cur ^ 1);
+        const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
+        const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pos = ((ks * 4 + fg) ^ (fr & 7)) * 16;
+            V8 af[MF], wf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const V8*)(sA + i * 16 * 128 + pos);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *(const V8*)(sB + j * 16 * 128 + pos);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
+        }
+        if (++ck == KT) {
+            const int tm = ct / p.tiles_n, tn = ct - tm * p.tiles_n;
+            if (p.geglu) {
+                if constexpr ((NF & 1) == 0) {
+                    idb_pl_epilogue<T, MF, NF, true>(p, acc, tm * BM, tn * BN, wm, wn, fr, fg);
+                    stores_in_flight = 2;
+                }
+            } else {
+                idb_pl_epilogue<T, MF, NF, false>(p, acc, tm * BM, tn * BN, wm, wn, fr, fg);
+                stores_in_flight = 1;
+            }
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ck = 0;
+            ct += G;
+        }
+    }
+#endif
+}
+
 // Split-K tail: sum the fp32 slabs and apply the same epilogue (bias, per-sample bias, residual).
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void idb_splitk_reduce_kernel(const float* __restrict__ partial, int splitk,
@@ -743,9 +930,13 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     pl->K = K;
     pl->ktiles = (int)(K / 64);
     int tile = d->tile % 10, ring3 = d->tile / 10;     // ring3: 0 -> 2-stage, 1 -> 3-stage, 2 -> 4-stage LDS ring
-    // ring3: 0 -> 2-stage LDS-DMA ring, 1 -> 3-stage, 2 -> 4-stage, 3 -> register-staged double buffer
-    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 3 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5),
-                "idb_gemm: tile id out of range");
+    // ring3: 0 -> 2-stage LDS-DMA ring, 1 -> 3-stage, 2 -> 4-stage, 3 -> register-staged double buffer, 4 -> persistent (plain matrices)
+    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 4 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
+                    !(ring3 == 4 && tile > 2), "idb_gemm: tile id out of range");
+    const bool plain = d->nsrc == 1 && d->src[0].taps == 1 && d->src[0].in_h == 1 && d->src[0].in_w == 1;
+    const bool pl_ok = plain && d->split_k <= 1 && d->out_dtype == d->dtype && (d->geglu ? d->n / 2 : d->n) % 4 == 0 &&
+                       d->out_ld % 4 == 0 && M * d->out_ld * 2 < (1LL << 31);
+    IDB_REQUIRE(ring3 != 4 || pl_ok, "idb_gemm: the persistent variant needs one plain [M][K] source, operand-dtype output < 2 GiB, no split-K");
     if (tile == 0) {
         const bool n160 = (d->n % 160 == 0) && !d->geglu;
         const int bn = d->n <= 32 ? 32 : (n160 ? 160 : 128);
@@ -768,6 +959,10 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     if (d->tile == 0) {
         static const int env_rs = [] { const char* e = getenv("IDB_GEMM_REGSTAGE"); return e ? atoi(e) : 0; }();
         if (env_rs) ring3 = 3;
+        static const int env_pl = [] { const char* e = getenv("IDB_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+        const long long tiles = ((M + 127) / 128) * ((d->n + (32 * kTiles[tile].nf) - 1) / (32 * kTiles[tile].nf));
+        // measured: +12-15 % on the GEGLU projections (N = 8C, K = C), neutral or slightly negative on the other K = C layers
+        if (env_pl && pl_ok && d->geglu && tile == 2 && pl->ktiles <= 24 && tiles >= 1536 && d->split_k <= 1) ring3 = 4;
     }
     pl->tile = tile + 10 * ring3;
     const int bm = 32 * kTiles[tile].mf, bn = 32 * kTiles[tile].nf;
@@ -786,6 +981,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
             if (sk < 1) sk = 1;
         }
     }
+    if (pl->tile / 10 == 4) sk = 1;
     IDB_REQUIRE(!(d->geglu && sk > 1), "idb_gemm: GEGLU does not support split-K");
     if (d->act) sk = 1;
     if (sk > pl->ktiles) sk = pl->ktiles;
@@ -832,6 +1028,25 @@ int launch_tile_rs(const GemmParams& p, const Plan& pl, hipStream_t st) {
     return IDB_OK;
 }
 
+template <typename T, int MF, int NF>
+int launch_tile_pl(const GemmParams& p, const Plan& pl, hipStream_t st) {
+    constexpr int LDS = (32 * MF + 32 * NF) * 128 * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_gemm_kernel_pl<T, MF, NF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            idb_set_error("idb_gemm: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
+            return IDB_EHIP;
+        }
+        attr_done = true;
+    }
+    const int tiles = pl.tiles_m * pl.tiles_n;
+    hipLaunchKernelGGL((idb_gemm_kernel_pl<T, MF, NF>), dim3(tiles < 512 ? tiles : 512), dim3(256), LDS, st, p);
+    IDB_CHECK_LAUNCH("idb_gemm(pl)");
+    return IDB_OK;
+}
+
 template <typename T>
 int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
     int rc;
@@ -844,6 +1059,8 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 12: rc = launch_tile<T, 4, 4, 3>(p, pl, st); break;
         case 13: rc = launch_tile<T, 2, 5, 3>(p, pl, st); break;
         case 14: rc = launch_tile<T, 2, 4, 3>(p, pl, st); break;
+        case 41: rc = launch_tile_pl<T, 4, 5>(p, pl, st); break;
+        case 42: rc = launch_tile_pl<T, 4, 4>(p, pl, st); break;
         case 31: rc = launch_tile_rs<T, 4, 5>(p, pl, st); break;
         case 32: rc = launch_tile_rs<T, 4, 4>(p, pl, st); break;
         case 33: rc = launch_tile_rs<T, 2, 5>(p, pl, st); break;
@@ -923,6 +1140,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.partial = (float*)workspace;
     p.tiles_n = pl.tiles_n;
     p.dbg_skip_store = (d->flags & 2) ? 1 : 0;
+    p.out_bytes = (unsigned)((long long)pl.M * d->out_ld * 2);
     p.act = d->act;
     {
         const int no = d->geglu ? d->n / 2 : d->n;
@@ -933,7 +1151,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
         const bool fused_reduce = pl.splitk > 1 && d->counters && (d->flags & 16) && !(d->flags & 8) && !(d->flags & 1) &&
                                   (long long)pl.tiles_m * pl.tiles_n <= d->counters_len;
         p.counters = fused_reduce ? d->counters : nullptr;
-        p.lds_epi = (!p.out_f32 && (pl.splitk == 1 || fused_reduce) && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&
+        p.lds_epi = (pl.tile / 10 != 4 && !p.out_f32 && (pl.splitk == 1 || fused_reduce) && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&
                      (!d->residual || idb_aligned16(d->residual))) ? 1 : 0;
     }
     hipStream_t st = (hipStream_t)stream;
