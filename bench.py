@@ -25,8 +25,18 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-TILE_NAMES = {1: "idb_gemm_kernel<128x160>", 2: "idb_gemm_kernel<128x128>", 3: "idb_gemm_kernel<64x160>",
-              4: "idb_gemm_kernel<64x128>", 5: "idb_gemm_kernel<128x32>"}
+_TILE_SHAPES = {1: "128x160", 2: "128x128", 3: "64x160", 4: "64x128", 5: "128x32"}
+_TILE_VARIANTS = {0: "idb_gemm_kernel<{},ring2>", 1: "idb_gemm_kernel<{},ring3>", 2: "idb_gemm_kernel<{},ring4>",
+                  3: "idb_gemm_kernel_rs<{}>", 4: "idb_gemm_kernel_pl<{}>"}
+
+
+class _TileNames(dict):
+    """idb_gemm_plan tile id -> kernel instance name (id = shape + 10 * variant, see idb_gemm.hip)."""
+    def __missing__(self, t):
+        return _TILE_VARIANTS[t // 10].format(_TILE_SHAPES[t % 10])
+
+
+TILE_NAMES = _TileNames()
 
 
 def parse():
