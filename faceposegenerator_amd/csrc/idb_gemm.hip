@@ -146,7 +146,8 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
         const int q = it * 256 + tid;
         const int row = q / CPR, c = q - row * CPR;
         const int m = m0 + row, n = n0o + c * 8;
-        if (m < p.M && n < No) *(V8*)((T*)p.out + (long long)m * p.out_ld + n) = *(const V8*)(smem + row * OLD + c * 16);
+        const int mo = p.dbg_skip_store == 2 ? (m & 127) : m;      // profiling: every tile writes the same L2-resident rows
+        if (m < p.M && n < No) *(V8*)((T*)p.out + (long long)mo * p.out_ld + n) = *(const V8*)(smem + row * OLD + c * 16);
     }
 }
 
@@ -155,7 +156,7 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
 template <typename T, int MF, int NF>
 __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
                                                   int wm, int wn, int fr, int fg) {
-    if (p.dbg_skip_store) {                 // profiling experiment: keep the accumulators live, write nothing
+    if (p.dbg_skip_store == 1) {            // profiling experiment: keep the accumulators live, write nothing
         float keep = 0.f;
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -323,8 +324,10 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
     }
 }
 
+// __launch_bounds__(256, 2): at most 256 VGPRs so that TWO workgroups share a CU — the second workgroup's MFMAs are what
+// hides this one's LDS-DMA issue, waits and epilogue (one workgroup per CU measured 0.70 vs 1.12 PFLOP/s on the conv shape).
 template <typename T, int MF, int NF, int NS>
-__global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 2) void idb_gemm_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
     using V8 = typename Op<T>::v8;
     constexpr int BM = 32 * MF, BN = 32 * NF, STAGE = (BM + BN) * 128;
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256) void idb_gemm_kernel(const GemmParams p) {
 typedef __attribute__((ext_vector_type(4))) unsigned idb_u32x4;
 
 template <typename T, int MF, int NF>
-__global__ __launch_bounds__(256) void idb_gemm_kernel_rs(const GemmParams p) {
+__global__ __launch_bounds__(256, 2) void idb_gemm_kernel_rs(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using V8 = typename Op<T>::v8;
     constexpr int BM = 32 * MF, BN = 32 * NF, STAGE = (BM + BN) * 128;
@@ -1139,7 +1142,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     p.partial = (float*)workspace;
     p.tiles_n = pl.tiles_n;
-    p.dbg_skip_store = (d->flags & 2) ? 1 : 0;
+    p.dbg_skip_store = (d->flags & 2) ? 1 : ((d->flags & 32) ? 2 : 0);
     p.out_bytes = (unsigned)((long long)pl.M * d->out_ld * 2);
     p.act = d->act;
     {
@@ -1148,7 +1151,9 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
         // sampling loop (batch 1: 4.49 vs 5.11 images/s): every split workgroup pays an agent-scope release (buffer_wbl2
         // of its XCD's L2) and one workgroup per tile re-reads all slabs — the "splitk-seam" price of the CDNA guide.
         // The path is kept, tested bit-identical to the two-launch form, for shapes where a launch boundary is dearer.
-        const bool fused_reduce = pl.splitk > 1 && d->counters && (d->flags & 16) && !(d->flags & 8) && !(d->flags & 1) &&
+        static const int env_fused = [] { const char* e = getenv("IDB_GEMM_FUSED_REDUCE"); return e ? atoi(e) : 0; }();
+        const bool want_fused = (d->flags & 16) || (env_fused > 0 && pl.splitk <= env_fused);
+        const bool fused_reduce = pl.splitk > 1 && d->counters && want_fused && !(d->flags & 8) && !(d->flags & 1) &&
                                   (long long)pl.tiles_m * pl.tiles_n <= d->counters_len;
         p.counters = fused_reduce ? d->counters : nullptr;
         p.lds_epi = (pl.tile / 10 != 4 && !p.out_f32 && (pl.splitk == 1 || fused_reduce) && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&

@@ -40,13 +40,15 @@ def main():
             m = be * side * side
             fl = 2.0 * m * cout * taps * cin
             res = []
-            for tile in ((1, 41, 2, 42, 0) if os.environ.get("IDB_KB_SHORT") else (1, 2, 3, 4, 11, 12, 13, 14, 0)):
+            for tile in ((1, 41, 2, 42, 100, 200) if os.environ.get("IDB_KB_SHORT") else (1, 2, 3, 4, 11, 12, 13, 14, 0)):
                 if cout % 160 and tile < 100 and tile % 10 in (1, 3):
                     continue
                 if tile // 10 == 4 and taps == 9:
                     continue
-                flags = 2 if tile >= 100 else 0           # 100/101: tile 1/2 with the epilogue stores skipped
-                tl = tile - 99 if tile >= 100 else tile
+                flags = 2 if 100 <= tile < 200 else (32 if tile >= 200 else 0)   # 100: stores skipped; 200: stores aliased to one tile
+                tl = 1 if tile >= 100 else tile
+                if tl // 10 == 4 and taps == 9:
+                    continue
                 def run():
                     eng.arena.reset()
                     if taps == 9:
