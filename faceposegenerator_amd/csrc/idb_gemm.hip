@@ -59,23 +59,23 @@ struct GemmParams {
 //   phase R (residual only): coalesced copy of the residual tile into LDS
 //   phase W: each lane adds bias / per-sample bias / residual (fp32, ONE rounding) and writes its 4-channel pieces in place
 //   phase S: coalesced LDS -> global stores
-template <typename T, int MF, int NF, bool GEGLU>
+template <typename T, int MF, int NF, bool GEGLU, int WM = 2>
 __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
                                                  int wm, int wn, int fr, int fg) {
     using V8 = typename Op<T>::v8;
     using V4 = typename Op<T>::v4;
-    constexpr int BM = 32 * MF, BN = 32 * NF;
+    constexpr int BM = 16 * MF * WM, BN = 32 * NF, THREADS = 128 * WM;
     constexpr int BNO = GEGLU ? BN / 2 : BN;          // output columns of this tile
     constexpr int OLD = BNO * 2 + 16;                  // LDS row stride (bytes), 16-B aligned, de-phased banks
     constexpr int CPR = BNO / 8;                       // 16-byte chunks per row
-    constexpr int ITER = BM * CPR / 256;
+    constexpr int ITER = BM * CPR / THREADS;
     const int No = GEGLU ? p.N / 2 : p.N;
     const int n0o = GEGLU ? n0 / 2 : n0;
     __syncthreads();                                   // every wave is done reading the last K tile
     if (p.res) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-            const int q = it * 256 + tid;
+            const int q = it * THREADS + tid;
             const int row = q / CPR, c = q - row * CPR;
             const int m = m0 + row, n = n0o + c * 8;
             if (m < p.M && n < No)
@@ -143,7 +143,7 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int q = it * 256 + tid;
+        const int q = it * THREADS + tid;
         const int row = q / CPR, c = q - row * CPR;
         const int m = m0 + row, n = n0o + c * 8;
         const int mo = p.dbg_skip_store == 2 ? (m & 127) : m;      // profiling: every tile writes the same L2-resident rows
@@ -153,7 +153,7 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
 
 // Everything after the K loop: LDS-staged coalesced epilogue for operand-dtype outputs, direct epilogue for fp32
 // outputs / split-K slabs / odd widths.
-template <typename T, int MF, int NF>
+template <typename T, int MF, int NF, int WM = 2>
 __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
                                                   int wm, int wn, int fr, int fg) {
     if (p.dbg_skip_store == 1) {            // profiling experiment: keep the accumulators live, write nothing
@@ -194,7 +194,7 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned* cnt = p.counters + (m0 / (32 * MF)) * p.tiles_n + n0 / (32 * NF);
+            unsigned* cnt = p.counters + (m0 / (16 * MF * WM)) * p.tiles_n + n0 / (32 * NF);
             const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool last = t == (unsigned)p.splitk - 1u;
             if (last) {
@@ -237,9 +237,9 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
     }
     if (p.lds_epi) {
         if (p.geglu) {
-            if constexpr ((NF & 1) == 0) idb_lds_epilogue<T, MF, NF, true>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+            if constexpr ((NF & 1) == 0) idb_lds_epilogue<T, MF, NF, true, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
         } else {
-            idb_lds_epilogue<T, MF, NF, false>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+            idb_lds_epilogue<T, MF, NF, false, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
         }
         return;
     }
@@ -326,11 +326,13 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
 
 // __launch_bounds__(256, 2): at most 256 VGPRs so that TWO workgroups share a CU — the second workgroup's MFMAs are what
 // hides this one's LDS-DMA issue, waits and epilogue (one workgroup per CU measured 0.70 vs 1.12 PFLOP/s on the conv shape).
-template <typename T, int MF, int NF, int NS>
-__global__ __launch_bounds__(256, 2) void idb_gemm_kernel(const GemmParams p) {
+template <typename T, int MF, int NF, int NS, int WM = 2>   // WM wave rows x 2 wave columns; tile = (16*MF*WM) x (32*NF)
+__global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
     using V8 = typename Op<T>::v8;
-    constexpr int BM = 32 * MF, BN = 32 * NF, STAGE = (BM + BN) * 128;
+    constexpr int BM = 16 * MF * WM, BN = 32 * NF, STAGE = (BM + BN) * 128;
+    constexpr int THREADS = 128 * WM, RS = 16 * WM;          // staging: RS tile rows per wave-instruction sweep of the workgroup
+    constexpr int NJ = (BN + RS - 1) / RS;                   // weight-row sweeps (the last one may be partial: 160 rows / 64)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel(const GemmParams p) {
     bool a_ok[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-        const int m = m0 + i * 32 + lrow;
+        const int m = m0 + i * RS + lrow;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
         if (p.HW == 1) {                     // plain [M][K] matrix: no pixel decode (two integer divisions per row)
@@ -373,11 +375,11 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel(const GemmParams p) {
     }
     // weights: one descriptor, per-row voffset fixed for the whole K loop, K position in the SGPR soffset
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
-    unsigned w_voff[NF];
+    unsigned w_voff[NJ];
 #pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int n = n0 + j * 32 + lrow;
-        w_voff[j] = n < p.N ? (unsigned)n * p.w_row_bytes + cg16 : IDB_OOB;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + j * RS + lrow;
+        w_voff[j] = (n < p.N && j * RS + lrow < BN) ? (unsigned)n * p.w_row_bytes + cg16 : IDB_OOB;
     }
     unsigned w_soff = (unsigned)kt0 * 128u;
 
@@ -432,10 +434,11 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel(const GemmParams p) {
         const unsigned a_soff = (unsigned)c0 * 2u;
 #pragma unroll
         for (int i = 0; i < MF; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(sA + (i * 256 + wave * 64) * 16), 16, a_voff[i], a_soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(sA + (i * THREADS + wave * 64) * 16), 16, a_voff[i], a_soff, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NF; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * 256 + wave * 64) * 16), 16, w_voff[j], w_soff, 0, 0);
+        for (int j = 0; j < NJ; ++j)
+            if (j * RS + wave * 8 < BN)       // wave-uniform: this wave's 8 rows of sweep j lie inside the tile
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * THREADS + wave * 64) * 16), 16, w_voff[j], w_soff, 0, 0);
         w_soff += 128u;
         c0 += 64;
         if (c0 == cur_c) {
@@ -457,7 +460,8 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel(const GemmParams p) {
     // ---- NS-deep LDS ring, one barrier per K-step.  At the top of iteration `it` tiles it .. it+NS-2 are in
     // flight; the counted vmcnt retires tile `it` (this wave's share), the barrier makes every wave's share
     // visible AND proves that all waves are done reading tile it-1, whose buffer the next DMA overwrites.
-    constexpr int LOADS = MF + NF;
+    constexpr int LOADS = MF + NJ;
+    static_assert(NS == 2 || NJ * RS == BN, "counted vmcnt needs the same number of loads in every wave");
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st)
         if (st < nk) stage(st);
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel(const GemmParams p) {
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
 
-    idb_gemm_epilogue<T, MF, NF>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
 #endif
 }
 
@@ -878,9 +882,9 @@ __global__ __launch_bounds__(256) void idb_splitk_reduce_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-struct TileCfg { int mf, nf; };
-const TileCfg kTiles[] = {{0, 0}, {4, 5}, {4, 4}, {2, 5}, {2, 4}, {4, 1}};   // index = desc.tile % 10
-constexpr int kNumTiles = 5;   // desc.tile = id (2-stage LDS ring) or 10 + id (3-stage ring, ids 1..4)
+struct TileCfg { int mf, nf, wm; };   // tile = (16*mf*wm) x (32*nf), 128*wm threads
+const TileCfg kTiles[] = {{0, 0, 2}, {4, 5, 2}, {4, 4, 2}, {2, 5, 2}, {2, 4, 2}, {4, 1, 2}, {4, 5, 4}, {4, 4, 4}};   // index = desc.tile % 10
+constexpr int kNumTiles = 7;   // desc.tile = id + 10 * variant; ids 6/7 = 256x160 / 256x128 with 8 waves (2-stage ring only)
 
 struct Plan {
     int tile, splitk, tiles_m, tiles_n, ktiles, kt_per_split, M;
@@ -935,7 +939,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     int tile = d->tile % 10, ring3 = d->tile / 10;     // ring3: 0 -> 2-stage, 1 -> 3-stage, 2 -> 4-stage LDS ring
     // ring3: 0 -> 2-stage LDS-DMA ring, 1 -> 3-stage, 2 -> 4-stage, 3 -> register-staged double buffer, 4 -> persistent (plain matrices)
     IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 4 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
-                    !(ring3 == 4 && tile > 2), "idb_gemm: tile id out of range");
+                    !(ring3 == 4 && tile > 2) && !(ring3 && tile >= 6), "idb_gemm: tile id out of range");
     const bool plain = d->nsrc == 1 && d->src[0].taps == 1 && d->src[0].in_h == 1 && d->src[0].in_w == 1;
     const bool pl_ok = plain && d->split_k <= 1 && d->out_dtype == d->dtype && (d->geglu ? d->n / 2 : d->n) % 4 == 0 &&
                        d->out_ld % 4 == 0 && M * d->out_ld * 2 < (1LL << 31);
@@ -968,7 +972,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         if (env_pl && pl_ok && d->geglu && tile == 2 && pl->ktiles <= 24 && tiles >= 1536 && d->split_k <= 1) ring3 = 4;
     }
     pl->tile = tile + 10 * ring3;
-    const int bm = 32 * kTiles[tile].mf, bn = 32 * kTiles[tile].nf;
+    const int bm = 16 * kTiles[tile].mf * kTiles[tile].wm, bn = 32 * kTiles[tile].nf;
     pl->tiles_m = (int)((M + bm - 1) / bm);
     pl->tiles_n = (d->n + bn - 1) / bn;
     const long long blocks = (long long)pl->tiles_m * pl->tiles_n;
@@ -993,12 +997,12 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     return IDB_OK;
 }
 
-template <typename T, int MF, int NF, int NS>
+template <typename T, int MF, int NF, int NS, int WM = 2>
 int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
-    constexpr int LDS = (32 * MF + 32 * NF) * 128 * NS;
+    constexpr int LDS = (16 * MF * WM + 32 * NF) * 128 * NS;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_gemm_kernel<T, MF, NF, NS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_gemm_kernel<T, MF, NF, NS, WM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             idb_set_error("idb_gemm: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
@@ -1007,7 +1011,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.splitk);
-    hipLaunchKernelGGL((idb_gemm_kernel<T, MF, NF, NS>), grid, dim3(256), LDS, st, p);
+    hipLaunchKernelGGL((idb_gemm_kernel<T, MF, NF, NS, WM>), grid, dim3(128 * WM), LDS, st, p);
     IDB_CHECK_LAUNCH("idb_gemm");
     return IDB_OK;
 }
@@ -1062,6 +1066,8 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 12: rc = launch_tile<T, 4, 4, 3>(p, pl, st); break;
         case 13: rc = launch_tile<T, 2, 5, 3>(p, pl, st); break;
         case 14: rc = launch_tile<T, 2, 4, 3>(p, pl, st); break;
+        case 6: rc = launch_tile<T, 4, 5, 2, 4>(p, pl, st); break;
+        case 7: rc = launch_tile<T, 4, 4, 2, 4>(p, pl, st); break;
         case 41: rc = launch_tile_pl<T, 4, 5>(p, pl, st); break;
         case 42: rc = launch_tile_pl<T, 4, 4>(p, pl, st); break;
         case 31: rc = launch_tile_rs<T, 4, 5>(p, pl, st); break;
