@@ -60,7 +60,12 @@ def cpu_baseline(pipe, ucfg, vcfg, lora_raw, ddpm_steps, size):
     """The oracle (CPU fp32 restatement) timed on the host cores on a bounded sample: 2 CFG UNet forwards (B_eff=2)
     and one VAE decode of the same graph and weights; extrapolated to one image = ddpm_steps forwards + 1 decode."""
     from oracle import sd21_oracle as O
-    cores = torch.get_num_threads()
+    try:
+        cores = len(os.sched_getaffinity(0))          # the CPUs this process may actually run on
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, torch.get_num_threads()))
+    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(1)
     lat = size // 8
     x = torch.randn(2, 4, lat, lat, generator=g)
