@@ -43,7 +43,7 @@ struct GemmParams {
     float scale;
     float* partial;
     int tiles_n;
-    int dbg_skip_store, lds_epi, act;
+    int dbg_skip_store, lds_epi, act, dbg_loop;   // dbg_loop (profiling): 1 = no MFMA/ds_read, 2 = no operand loads
     unsigned* counters;   // non-null: in-kernel split-K reduce
     unsigned out_bytes;   // persistent variant: size of the output tensor (buffer range check drops masked stores)
 };
@@ -471,7 +471,11 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * LOADS) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (it + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1);
+        if (it + NS - 1 < nk && p.dbg_loop != 2) stage(cur == 0 ? NS - 1 : cur - 1);
+        if (p.dbg_loop == 1) {
+            cur = cur + 1 == NS ? 0 : cur + 1;
+            continue;
+        }
         const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
         const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
 #pragma unroll
@@ -883,8 +887,11 @@ __global__ __launch_bounds__(256) void idb_splitk_reduce_kernel(const float* __r
 namespace {
 
 struct TileCfg { int mf, nf, wm; };   // tile = (16*mf*wm) x (32*nf), 128*wm threads
-const TileCfg kTiles[] = {{0, 0, 2}, {4, 5, 2}, {4, 4, 2}, {2, 5, 2}, {2, 4, 2}, {4, 1, 2}, {4, 5, 4}, {4, 4, 4}};   // index = desc.tile % 10
-constexpr int kNumTiles = 7;   // desc.tile = id + 10 * variant; ids 6/7 = 256x160 / 256x128 with 8 waves (2-stage ring only)
+const TileCfg kTiles[] = {{0, 0, 2}, {4, 5, 2}, {4, 4, 2}, {2, 5, 2}, {2, 4, 2}, {4, 1, 2},
+                          {4, 5, 4}, {1, 4, 4}, {2, 5, 4}, {2, 4, 4}};   // index = desc.tile % 10
+// desc.tile = id + 10 * variant.  ids 6-9 have 8 waves per workgroup (2-stage ring only): 6 = 256x160, 7 = 64x128,
+// 8 = 128x160, 9 = 128x128 — the same tiles as 4/1/2 with half the LDS-DMA instructions per wave and K-step.
+constexpr int kNumTiles = 9;
 
 struct Plan {
     int tile, splitk, tiles_m, tiles_n, ktiles, kt_per_split, M;
@@ -952,9 +959,15 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         //  * enough work for >= 2 workgroups per CU: 128-row tiles (highest FLOP per byte moved L2 -> LDS);
         //  * weight-streaming layers (M <= 2048, long K): 128-row tiles + split-K, each weight tile read by few workgroups;
         //  * everything else (the batch-1 projection GEMMs and 64x64-level convs): 64-row tiles so that all CUs get work.
+        //  * short K loops (<= 10 K-steps): the 8-wave forms of the same tiles (ids 7/8/9) — the K-step of a lone workgroup is
+        //    the issue time of its LDS-DMA instructions plus one memory round trip (tools/bench_latency.py: unchanged with
+        //    the MFMAs removed), and 8 waves halve the DMA instructions each wave issues.
+        const bool short_k = pl->ktiles <= 10;
         if (d->n <= 32) tile = 5;
-        else if (blocks_big >= 512 || (M <= 2048 && pl->ktiles >= 64)) tile = n160 ? 1 : 2;
-        else tile = (n160 && pl->ktiles >= 32) ? 3 : 4;
+        else if (blocks_big >= 512 || (M <= 2048 && pl->ktiles >= 64)) tile = short_k ? (n160 ? 8 : 9) : (n160 ? 1 : 2);
+        else if (short_k && M >= 4096) tile = 9;
+        else if (d->geglu && blocks_big >= 256) tile = 2;      // wide N = 8C, no split-K possible: 128-row tiles (persistent form below)
+        else tile = (n160 && pl->ktiles >= 32) ? 3 : 7;
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
     if (d->tile == 0 && tile != 5) {
@@ -969,7 +982,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         static const int env_pl = [] { const char* e = getenv("IDB_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
         const long long tiles = ((M + 127) / 128) * ((d->n + (32 * kTiles[tile].nf) - 1) / (32 * kTiles[tile].nf));
         // measured: +12-15 % on the GEGLU projections (N = 8C, K = C), neutral or slightly negative on the other K = C layers
-        if (env_pl && pl_ok && d->geglu && tile == 2 && pl->ktiles <= 24 && tiles >= 1536 && d->split_k <= 1) ring3 = 4;
+        if (env_pl && pl_ok && d->geglu && tile == 2 && pl->ktiles <= 24 && tiles >= 256 && d->split_k <= 1) ring3 = 4;
     }
     pl->tile = tile + 10 * ring3;
     const int bm = 16 * kTiles[tile].mf * kTiles[tile].wm, bn = 32 * kTiles[tile].nf;
@@ -982,7 +995,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         sk = 1;
         if (!d->geglu && blocks < 192 && pl->ktiles >= 10) {
             sk = (int)((384 + blocks - 1) / blocks);
-            const int max_by_k = pl->ktiles / (kTiles[tile].mf == 2 ? 5 : 8);   // K-steps per split: >= 5 (64-row) / 8 (128-row)
+            const int max_by_k = pl->ktiles / (kTiles[tile].mf * kTiles[tile].wm <= 4 ? 5 : 8);   // K-steps per split: >= 5 (64-row) / 8 (128-row)
             if (sk > max_by_k) sk = max_by_k;
             if (sk > 32) sk = 32;
             if (sk < 1) sk = 1;
@@ -1067,7 +1080,9 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 13: rc = launch_tile<T, 2, 5, 3>(p, pl, st); break;
         case 14: rc = launch_tile<T, 2, 4, 3>(p, pl, st); break;
         case 6: rc = launch_tile<T, 4, 5, 2, 4>(p, pl, st); break;
-        case 7: rc = launch_tile<T, 4, 4, 2, 4>(p, pl, st); break;
+        case 7: rc = launch_tile<T, 1, 4, 2, 4>(p, pl, st); break;
+        case 8: rc = launch_tile<T, 2, 5, 2, 4>(p, pl, st); break;
+        case 9: rc = launch_tile<T, 2, 4, 2, 4>(p, pl, st); break;
         case 41: rc = launch_tile_pl<T, 4, 5>(p, pl, st); break;
         case 42: rc = launch_tile_pl<T, 4, 4>(p, pl, st); break;
         case 31: rc = launch_tile_rs<T, 4, 5>(p, pl, st); break;
@@ -1151,6 +1166,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.dbg_skip_store = (d->flags & 2) ? 1 : ((d->flags & 32) ? 2 : 0);
     p.out_bytes = (unsigned)((long long)pl.M * d->out_ld * 2);
     p.act = d->act;
+    p.dbg_loop = (d->flags & 64) ? 1 : ((d->flags & 128) ? 2 : 0);
     {
         const int no = d->geglu ? d->n / 2 : d->n;
         // In-kernel split-K reduce (flags bit 4 only).  Measured on MI355X it LOSES to the separate reduce launch in the

@@ -15,9 +15,9 @@ for (m, n) in ((512, 1280), (128, 1280), (2048, 640), (8192, 320)):
         ws = [(torch.randn(n, k, device=dev) * k ** -0.5).to(eng.tdt) for _ in range(nbuf)]
         x = torch.randn(m, k, device=dev).to(eng.tdt)
         out = torch.empty(m, n, dtype=eng.tdt, device=dev)
-        for sk in (1, 0):
+        for sk, fl in ((1, 0), (1, 64), (1, 128), (0, 0)):
             def run(i):
-                eng.gemm([(x, k, 1, 1, 1, 0)], ws[i % nbuf], n, m, 1, 1, out=out, split_k=sk)
+                eng.gemm([(x, k, 1, 1, 1, 0)], ws[i % nbuf], n, m, 1, 1, out=out, split_k=sk, flags=fl)
             for i in range(nbuf): run(i)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -27,6 +27,6 @@ for (m, n) in ((512, 1280), (128, 1280), (2048, 640), (8192, 320)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); g.replay(); g.replay(); e1.record(); torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / (2 * nbuf) * 1e3
-            print(f"m={m:5d} n={n:5d} k={k:6d} ksteps={k // 64:4d} split={'auto' if sk == 0 else 1:>4} : {t:7.1f} us/launch  "
+            print(f"m={m:5d} n={n:5d} k={k:6d} ksteps={k // 64:4d} split={'auto' if sk == 0 else 1:>4} {'noMFMA' if fl == 64 else 'noLOAD' if fl == 128 else 'full  '} : {t:7.1f} us/launch  "
                   f"{2.0 * m * n * k / t / 1e6:7.1f} TF/s  weights {n * k * 2 / 1e6:6.1f} MB -> {n * k * 2 / t / 1e6:6.2f} TB/s")
         del ws

@@ -16,8 +16,8 @@ for (m, n, k) in shapes:
     res = torch.randn(m, n, device=dev).to(eng.tdt)
     out = torch.empty(m, n, dtype=eng.tdt, device=dev)
     line = []
-    for tile, sk in ((1, 1), (3, 1), (2, 1), (4, 1), (1, 2), (1, 4), (3, 2), (4, 2), (4, 4), (0, 0)):
-        if n % 160 and tile in (1, 3):
+    for tile, sk in ((4, 1), (7, 1), (9, 1), (8, 1), (4, 2), (7, 2), (9, 2), (4, 4), (7, 4), (9, 4), (0, 0)):
+        if n % 160 and tile in (1, 3, 8):
             continue
         if sk > 1 and k // 64 < 2 * sk:
             continue
