@@ -68,7 +68,7 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
     constexpr int BNO = GEGLU ? BN / 2 : BN;          // output columns of this tile
     constexpr int OLD = BNO * 2 + 16;                  // LDS row stride (bytes), 16-B aligned, de-phased banks
     constexpr int CPR = BNO / 8;                       // 16-byte chunks per row
-    constexpr int ITER = BM * CPR / THREADS;
+    constexpr int NCHUNK = BM * CPR, ITER = (NCHUNK + THREADS - 1) / THREADS;
     const int No = GEGLU ? p.N / 2 : p.N;
     const int n0o = GEGLU ? n0 / 2 : n0;
     __syncthreads();                                   // every wave is done reading the last K tile
@@ -78,7 +78,7 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
             const int q = it * THREADS + tid;
             const int row = q / CPR, c = q - row * CPR;
             const int m = m0 + row, n = n0o + c * 8;
-            if (m < p.M && n < No)
+            if (q < NCHUNK && m < p.M && n < No)
                 *(V8*)(smem + row * OLD + c * 16) = *(const V8*)((const T*)p.res + (long long)m * p.out_ld + n);
         }
         __syncthreads();
@@ -147,7 +147,7 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
         const int row = q / CPR, c = q - row * CPR;
         const int m = m0 + row, n = n0o + c * 8;
         const int mo = p.dbg_skip_store == 2 ? (m & 127) : m;      // profiling: every tile writes the same L2-resident rows
-        if (m < p.M && n < No) *(V8*)((T*)p.out + (long long)mo * p.out_ld + n) = *(const V8*)(smem + row * OLD + c * 16);
+        if (q < NCHUNK && m < p.M && n < No) *(V8*)((T*)p.out + (long long)mo * p.out_ld + n) = *(const V8*)(smem + row * OLD + c * 16);
     }
 }
 
@@ -888,9 +888,10 @@ namespace {
 
 struct TileCfg { int mf, nf, wm; };   // tile = (16*mf*wm) x (32*nf), 128*wm threads
 const TileCfg kTiles[] = {{0, 0, 2}, {4, 5, 2}, {4, 4, 2}, {2, 5, 2}, {2, 4, 2}, {4, 1, 2},
-                          {4, 5, 4}, {1, 4, 4}, {2, 5, 4}, {2, 4, 4}};   // index = desc.tile % 10
-// desc.tile = id + 10 * variant.  ids 6-9 have 8 waves per workgroup (2-stage ring only): 6 = 256x160, 7 = 64x128,
-// 8 = 128x160, 9 = 128x128 — the same tiles as 4/1/2 with half the LDS-DMA instructions per wave and K-step.
+                          {1, 5, 4}, {1, 4, 4}, {2, 5, 4}, {2, 4, 4}};   // index = desc.tile % 10
+// desc.tile = id + 10 * variant.  ids 6-9 have 8 waves per workgroup (2-stage ring only): 6 = 64x160, 7 = 64x128,
+// 8 = 128x160, 9 = 128x128 — the same tiles as 3/4/1/2 with half the LDS-DMA instructions per wave and K-step
+// (a 256x160 tile with 8 waves was measured 3-8 % slower than 128x160 with two workgroups per CU and is not kept).
 constexpr int kNumTiles = 9;
 
 struct Plan {
@@ -964,10 +965,10 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         //    the MFMAs removed), and 8 waves halve the DMA instructions each wave issues.
         const bool short_k = pl->ktiles <= 10;
         if (d->n <= 32) tile = 5;
-        else if (blocks_big >= 512 || (M <= 2048 && pl->ktiles >= 64)) tile = short_k ? (n160 ? 8 : 9) : (n160 ? 1 : 2);
+        else if (d->geglu && blocks_big >= 256) tile = pl->ktiles >= 16 ? 2 : 9;   // N = 8C, no split-K: 128-row (persistent form for K >= 1024)
+        else if (blocks_big >= 512 || (M <= 2048 && pl->ktiles >= 64)) tile = n160 ? 8 : 9;   // 8-wave 128-row tiles: >= the 4-wave forms on every measured shape
         else if (short_k && M >= 4096) tile = 9;
-        else if (d->geglu && blocks_big >= 256) tile = 2;      // wide N = 8C, no split-K possible: 128-row tiles (persistent form below)
-        else tile = (n160 && pl->ktiles >= 32) ? 3 : 7;
+        else tile = (n160 && pl->ktiles >= 32) ? (M >= 4096 ? 6 : 3) : 7;
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
     if (d->tile == 0 && tile != 5) {
@@ -1079,7 +1080,7 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 12: rc = launch_tile<T, 4, 4, 3>(p, pl, st); break;
         case 13: rc = launch_tile<T, 2, 5, 3>(p, pl, st); break;
         case 14: rc = launch_tile<T, 2, 4, 3>(p, pl, st); break;
-        case 6: rc = launch_tile<T, 4, 5, 2, 4>(p, pl, st); break;
+        case 6: rc = launch_tile<T, 1, 5, 2, 4>(p, pl, st); break;
         case 7: rc = launch_tile<T, 1, 4, 2, 4>(p, pl, st); break;
         case 8: rc = launch_tile<T, 2, 5, 2, 4>(p, pl, st); break;
         case 9: rc = launch_tile<T, 2, 4, 2, 4>(p, pl, st); break;
