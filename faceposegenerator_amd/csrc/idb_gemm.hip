@@ -330,9 +330,11 @@ template <typename T, int MF, int NF, int NS, int WM = 2>   // WM wave rows x 2 
 __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
     using V8 = typename Op<T>::v8;
-    constexpr int BM = 16 * MF * WM, BN = 32 * NF, STAGE = (BM + BN) * 128;
+    constexpr int BM = 16 * MF * WM, BN = 32 * NF;
     constexpr int THREADS = 128 * WM, RS = 16 * WM;          // staging: RS tile rows per wave-instruction sweep of the workgroup
-    constexpr int NJ = (BN + RS - 1) / RS;                   // weight-row sweeps (the last one may be partial: 160 rows / 64)
+    constexpr int NJ = (BN + RS - 1) / RS;                   // weight-row sweeps; the last may be partial (160 rows / 64): its surplus
+    constexpr int STAGE = (BM + NJ * RS) * 128;              // rows are LDS padding filled with zeros (out-of-range voffset), so every
+                                                             // wave issues the same number of loads and the counted vmcnt stays exact
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -437,8 +439,7 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(sA + (i * THREADS + wave * 64) * 16), 16, a_voff[i], a_soff, 0, 0);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            if (j * RS + wave * 8 < BN)       // wave-uniform: this wave's 8 rows of sweep j lie inside the tile
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * THREADS + wave * 64) * 16), 16, w_voff[j], w_soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * THREADS + wave * 64) * 16), 16, w_voff[j], w_soff, 0, 0);
         w_soff += 128u;
         c0 += 64;
         if (c0 == cur_c) {
@@ -461,7 +462,6 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
     // flight; the counted vmcnt retires tile `it` (this wave's share), the barrier makes every wave's share
     // visible AND proves that all waves are done reading tile it-1, whose buffer the next DMA overwrites.
     constexpr int LOADS = MF + NJ;
-    static_assert(NS == 2 || NJ * RS == BN, "counted vmcnt needs the same number of loads in every wave");
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st)
         if (st < nk) stage(st);
@@ -947,7 +947,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     int tile = d->tile % 10, ring3 = d->tile / 10;     // ring3: 0 -> 2-stage, 1 -> 3-stage, 2 -> 4-stage LDS ring
     // ring3: 0 -> 2-stage LDS-DMA ring, 1 -> 3-stage, 2 -> 4-stage, 3 -> register-staged double buffer, 4 -> persistent (plain matrices)
     IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 4 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
-                    !(ring3 == 4 && tile > 2) && !(ring3 && tile >= 6), "idb_gemm: tile id out of range");
+                    !(ring3 == 4 && tile > 2) && !(ring3 && tile >= 6 && ring3 != 1), "idb_gemm: tile id out of range");
     const bool plain = d->nsrc == 1 && d->src[0].taps == 1 && d->src[0].in_h == 1 && d->src[0].in_w == 1;
     const bool pl_ok = plain && d->split_k <= 1 && d->out_dtype == d->dtype && (d->geglu ? d->n / 2 : d->n) % 4 == 0 &&
                        d->out_ld % 4 == 0 && M * d->out_ld * 2 < (1LL << 31);
@@ -969,6 +969,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         else if (blocks_big >= 512 || (M <= 2048 && pl->ktiles >= 64)) tile = n160 ? 8 : 9;   // 8-wave 128-row tiles: >= the 4-wave forms on every measured shape
         else if (short_k && M >= 4096) tile = 9;
         else tile = (n160 && pl->ktiles >= 32) ? (M >= 4096 ? 6 : 3) : 7;
+        if (tile == 7 && M <= 2048) ring3 = 1;    // lone workgroup per CU: a 3-deep ring hides the memory round trip (8 waves: short DMA issue)
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
     if (d->tile == 0 && tile != 5) {
@@ -994,7 +995,15 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     int sk = d->split_k;
     if (sk <= 0) {
         sk = 1;
-        if (!d->geglu && blocks < 192 && pl->ktiles >= 10) {
+        const bool small_tile = kTiles[tile].mf * kTiles[tile].wm <= 4;     // 64-row tiles
+        if (!d->geglu && small_tile && blocks < 96 && pl->ktiles >= 16) {
+            // measured (tools/bench_small.py): with the 3-deep ring a short K loop is cheaper than a split + reduce launch
+            sk = (int)((256 + blocks - 1) / blocks);
+            const int max_by_k = pl->ktiles / 5;
+            if (sk > max_by_k) sk = max_by_k;
+            if (sk > 32) sk = 32;
+            if (sk < 1) sk = 1;
+        } else if (!d->geglu && !small_tile && blocks < 192 && pl->ktiles >= 10) {
             sk = (int)((384 + blocks - 1) / blocks);
             const int max_by_k = pl->ktiles / (kTiles[tile].mf * kTiles[tile].wm <= 4 ? 5 : 8);   // K-steps per split: >= 5 (64-row) / 8 (128-row)
             if (sk > max_by_k) sk = max_by_k;
@@ -1013,7 +1022,8 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
 
 template <typename T, int MF, int NF, int NS, int WM = 2>
 int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
-    constexpr int LDS = (16 * MF * WM + 32 * NF) * 128 * NS;
+    constexpr int RS = 16 * WM, NJ = (32 * NF + RS - 1) / RS;
+    constexpr int LDS = (16 * MF * WM + NJ * RS) * 128 * NS;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_gemm_kernel<T, MF, NF, NS, WM>),
@@ -1083,6 +1093,10 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 6: rc = launch_tile<T, 1, 5, 2, 4>(p, pl, st); break;
         case 7: rc = launch_tile<T, 1, 4, 2, 4>(p, pl, st); break;
         case 8: rc = launch_tile<T, 2, 5, 2, 4>(p, pl, st); break;
+        case 16: rc = launch_tile<T, 1, 5, 3, 4>(p, pl, st); break;
+        case 18: rc = launch_tile<T, 2, 5, 3, 4>(p, pl, st); break;
+        case 17: rc = launch_tile<T, 1, 4, 3, 4>(p, pl, st); break;
+        case 19: rc = launch_tile<T, 2, 4, 3, 4>(p, pl, st); break;
         case 9: rc = launch_tile<T, 2, 4, 2, 4>(p, pl, st); break;
         case 41: rc = launch_tile_pl<T, 4, 5>(p, pl, st); break;
         case 42: rc = launch_tile_pl<T, 4, 4>(p, pl, st); break;

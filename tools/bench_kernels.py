@@ -40,7 +40,7 @@ def main():
             m = be * side * side
             fl = 2.0 * m * cout * taps * cin
             res = []
-            for tile in ((8, 1, 8, 1, 9, 2) if os.environ.get("IDB_KB_SHORT") else (1, 2, 3, 4, 11, 12, 13, 14, 0)):
+            for tile in ((6, 16, 3, 8, 18, 0) if os.environ.get("IDB_KB_SHORT") else (1, 2, 3, 4, 11, 12, 13, 14, 0)):
                 if cout % 160 and tile < 100 and tile % 10 in (1, 3, 6, 8):
                     continue
                 if tile // 10 == 4 and taps == 9:
