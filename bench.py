@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-_TILE_SHAPES = {1: "128x160", 2: "128x128", 3: "64x160", 4: "64x128", 5: "128x32"}
+_TILE_SHAPES = {1: "128x160", 2: "128x128", 3: "64x160", 4: "64x128", 5: "128x32",
+                6: "64x160,8w", 7: "64x128,8w", 8: "128x160,8w", 9: "128x128,8w"}
 _TILE_VARIANTS = {0: "idb_gemm_kernel<{},ring2>", 1: "idb_gemm_kernel<{},ring3>", 2: "idb_gemm_kernel<{},ring4>",
                   3: "idb_gemm_kernel_rs<{}>", 4: "idb_gemm_kernel_pl<{}>"}
 
@@ -89,10 +90,13 @@ def cpu_baseline(pipe, ucfg, vcfg, lora_raw, ddpm_steps, size):
 
 def kernel_roofline(eng, batch, lat_side, n_ctx):
     """Device duration of every implicit-GEMM launch of ONE CFG UNet forward, measured with HIP events on the launch
-    stream: an eager forward records each launch's descriptor, then every descriptor is re-launched REPS times
-    back-to-back between two events (queue saturated, so no host-launch gaps; the split-K reduce launch is skipped by
-    the descriptor's profiling flag so that the figure is the idb_gemm_kernel instance alone, as rocprofv3 lists it).
-    The tile configuration with the largest summed duration is the dominant kernel."""
+    stream: an eager forward records each launch's descriptor; the recorded sequence is then replayed IN ORDER, REPS times,
+    with an event pair around every launch (in order, so that each launch finds its weights as cold as in the sampling
+    loop: a forward reads 1.7 GB of weights, far more than L2 + MALL hold; re-launching one descriptor back-to-back would
+    time it with warm weights).  The split-K reduce launch is skipped by the descriptor's profiling flag so that the
+    figure is the idb_gemm_kernel instance alone, as rocprofv3 lists it.  The duration of an EMPTY event pair (marker
+    dispatch, measured here too) is subtracted.  The tile configuration with the largest summed duration is the dominant
+    kernel."""
     import ctypes as C
     from faceposegenerator_amd import _lib as L
     REPS = 5
@@ -110,24 +114,37 @@ def kernel_roofline(eng, batch, lat_side, n_ctx):
     torch.cuda.synchronize()
     log, eng.launch_log = eng.launch_log, None
     st = torch.cuda.current_stream().cuda_stream
+
+    def pair():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
     for e in log:
-        d = e["desc"]
-        d.flags = 1
-        ws, need = e["ws"]
-        wsp = None if ws is None else ws.data_ptr()
-        L.check(eng.lib.idb_gemm(C.byref(d), wsp, need, st))            # warm
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(REPS):
-            L.check(eng.lib.idb_gemm(C.byref(d), wsp, need, st))
-        ev1.record()
-        e["ev"] = (ev0, ev1)
+        e["desc"].flags = 1
+        e["ev"] = []
+    empty = []
+    for r in range(REPS + 1):                                            # pass 0 = warm-up, untimed
+        for e in log:
+            ws, need = e["ws"]
+            ev0, ev1 = pair()
+            ev0.record()
+            L.check(eng.lib.idb_gemm(C.byref(e["desc"]), None if ws is None else ws.data_ptr(), need, st))
+            ev1.record()
+            if r:
+                e["ev"].append((ev0, ev1))
+        for _ in range(8):
+            ev0, ev1 = pair()
+            ev0.record()
+            ev1.record()
+            if r:
+                empty.append((ev0, ev1))
     torch.cuda.synchronize()
+    overhead_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
     agg = {}
     for e in log:
-        e["ms"] = e["ev"][0].elapsed_time(e["ev"][1]) / REPS
-        a = agg.setdefault(e["tile"], {"flops": 0.0, "ms": 0.0, "n": 0})
+        e["ms"] = max(sum(a.elapsed_time(b) for a, b in e["ev"]) / REPS - overhead_ms, 1e-4)
+        a = agg.setdefault(e["tile"], {"flops": 0.0, "ms": 0.0, "n": 0, "bytes": 0.0})
         a["flops"] += e["flops"]
+        a["bytes"] += e["bytes"]
         a["ms"] += e["ms"]
         a["n"] += 1
     if os.environ.get("IDB_DUMP_GEMM"):
@@ -150,9 +167,28 @@ def kernel_roofline(eng, batch, lat_side, n_ctx):
                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for t, v in sorted(agg.items())}
     return {"bound": "mfma", "kernel": TILE_NAMES[dom], "achieved": round(achieved, 1), "peak": PEAK_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch_avg": round(a["bytes"] / a["n"], 1),
             "launches_per_forward": a["n"], "avg_launch_us": round(a["ms"] * 1e3 / a["n"], 2),
-            "flops_per_launch_avg": round(a["flops"] / a["n"], 1),
+            "flops_per_launch_avg": round(a["flops"] / a["n"], 1), "event_pair_overhead_us": round(overhead_ms * 1e3, 2),
             "all_gemm_tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 1), "per_tile": detail}
+
+
+def attach_pmc_traffic(roof, batch, args):
+    """`traffic`: HBM bytes per launch of the dominant kernel from the PMC pass over THIS command (rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs, 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for
+    gfx950; summarised by tools/pmc_summary.py into profiles/<round>/pmc_bench_b1_traffic.json).  Counters cannot be read
+    from inside the process, so the committed summary of the default workload is attached; any other workload -> null."""
+    if batch != 1 or args.dtype != "bf16" or args.tiny or args.ddpm_steps != 30 or args.size != 512:
+        return
+    here = os.path.dirname(os.path.abspath(__file__))
+    for rnd in sorted(os.listdir(os.path.join(here, "profiles")), reverse=True):
+        f = os.path.join(here, "profiles", rnd, "pmc_bench_b1_traffic.json")
+        if os.path.isfile(f):
+            e = json.load(open(f)).get(roof["kernel"])
+            if e and "hbm_bytes_per_launch" in e:
+                roof["traffic"] = round(e["hbm_bytes_per_launch"], 1)
+                roof["traffic_source"] = f"profiles/{rnd}/pmc_bench_b1_traffic.json (bytes per launch, {int(e['launches'])} launches)"
+            return
 
 
 def main():
@@ -249,6 +285,7 @@ def main():
         }
         if not args.no_kernel_roofline:
             res["roofline"] = kernel_roofline(eng, B, lat_side, 77)
+            attach_pmc_traffic(res["roofline"], B, args)
         else:
             res["roofline"] = {"bound": "mfma", "achieved": round(path_tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(path_tflops / PEAK_MFMA_TFLOPS, 4), "traffic": None}

@@ -7,8 +7,11 @@ for f in sys.argv[1:]:
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     for r in rows[:16]:
         n = r["Name"]
-        m = re.search(r"idb_gemm_kernelIDF16(.)Li(\d)ELi(\d)ELi(\d)", n)
-        if m: n = f"idb_gemm_kernel<{'bf16' if m.group(1)=='b' else 'f16'},{32*int(m.group(2))}x{32*int(m.group(3))},ring{m.group(4)}>"
+        m = re.search(r"idb_gemm_kernel(_rs|_pl)?I(DF16b|DF16_)Li(\d)ELi(\d)E(?:Li(\d)E)?(?:Li(\d)E)?", n)
+        if m:
+            wm = int(m.group(6) or 2)
+            n = (f"idb_gemm_kernel{m.group(1) or ''}<{'bf16' if m.group(2) == 'DF16b' else 'f16'},{16 * wm * int(m.group(3))}x{32 * int(m.group(4))}"
+                 f",{2 * wm}w" + (f",ring{m.group(5)}>" if m.group(5) else ">"))
         else:
             m = re.search(r"\d+([a-z_0-9]+_kernel)", n)
             n = m.group(1) if m else n[:48]
