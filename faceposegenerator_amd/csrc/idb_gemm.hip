@@ -947,29 +947,53 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     int tile = d->tile % 10, ring3 = d->tile / 10;     // ring3: 0 -> 2-stage, 1 -> 3-stage, 2 -> 4-stage LDS ring
     // ring3: 0 -> 2-stage LDS-DMA ring, 1 -> 3-stage, 2 -> 4-stage, 3 -> register-staged double buffer, 4 -> persistent (plain matrices)
     IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 4 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
-                    !(ring3 == 4 && tile > 2) && !(ring3 && tile >= 6 && ring3 != 1), "idb_gemm: tile id out of range");
+                    !(ring3 == 4 && tile > 2) && !(ring3 > 1 && tile >= 6), "idb_gemm: tile id out of range");
     const bool plain = d->nsrc == 1 && d->src[0].taps == 1 && d->src[0].in_h == 1 && d->src[0].in_w == 1;
     const bool pl_ok = plain && d->split_k <= 1 && d->out_dtype == d->dtype && (d->geglu ? d->n / 2 : d->n) % 4 == 0 &&
                        d->out_ld % 4 == 0 && M * d->out_ld * 2 < (1LL << 31);
     IDB_REQUIRE(ring3 != 4 || pl_ok, "idb_gemm: the persistent variant needs one plain [M][K] source, operand-dtype output < 2 GiB, no split-K");
+    int auto_sk = 0;                                    // split-K chosen together with the tile (0: by the rules below)
     if (tile == 0) {
         const bool n160 = (d->n % 160 == 0) && !d->geglu;
         const int bn = d->n <= 32 ? 32 : (n160 ? 160 : 128);
         const long long blocks_big = ((M + 127) / 128) * ((d->n + bn - 1) / bn);
-        // measured on MI355X (tools/bench_kernels.py, tools/bench_small.py with HBM-cold weights inside a HIP graph):
-        //  * enough work for >= 2 workgroups per CU: 128-row tiles (highest FLOP per byte moved L2 -> LDS);
-        //  * weight-streaming layers (M <= 2048, long K): 128-row tiles + split-K, each weight tile read by few workgroups;
-        //  * everything else (the batch-1 projection GEMMs and 64x64-level convs): 64-row tiles so that all CUs get work.
-        //  * short K loops (<= 10 K-steps): the 8-wave forms of the same tiles (ids 7/8/9) — the K-step of a lone workgroup is
-        //    the issue time of its LDS-DMA instructions plus one memory round trip (tools/bench_latency.py: unchanged with
-        //    the MFMAs removed), and 8 waves halve the DMA instructions each wave issues.
+        const long long blocks64 = ((M + 63) / 64) * ((d->n + 127) / 128);
+        // measured on MI355X with HBM-cold operands inside a HIP graph (tools/bench_conv.py, tools/bench_small.py; warm
+        // back-to-back timings rank the variants differently and mislead):
+        //  * >= 2 workgroups per CU: 128-row 8-wave tiles, 2-deep ring (two co-resident workgroups hide each other's latency);
+        //  * at most ONE workgroup per CU (the whole batch-1 UNet): the K-step of a lone workgroup is the issue time of its
+        //    LDS-DMA instructions plus one memory round trip (tools/bench_latency.py: unchanged with the MFMAs removed), so
+        //    8 waves (half the DMA instructions per wave) and a 3-deep ring (two K-steps in flight): -25...-45 % per launch;
+        //  * long K (convs, the big FF projections): 128x160 ring-3 tile, split-K to one workgroup per CU (256 / blocks; 384
+        //    blocks = 1.5 rounds is worse than 256 or 512), at least 8 K-steps per split; if that cannot fill half the chip
+        //    (M = 128) the 64x128 ring-3 tile with the same rule;
+        //  * short K: 64-row ring-3 tiles, split only for tiny grids (the reduce launch costs more than a short K loop).
         const bool short_k = pl->ktiles <= 10;
         if (d->n <= 32) tile = 5;
         else if (d->geglu && blocks_big >= 256) tile = pl->ktiles >= 16 ? 2 : 9;   // N = 8C, no split-K: 128-row (persistent form for K >= 1024)
-        else if (blocks_big >= 512 || (M <= 2048 && pl->ktiles >= 64)) tile = n160 ? 8 : 9;   // 8-wave 128-row tiles: >= the 4-wave forms on every measured shape
-        else if (short_k && M >= 4096) tile = 9;
+        else if (blocks_big >= 512) tile = n160 ? 8 : 9;
+        else if (!d->geglu && pl->ktiles >= 32 && blocks_big < 256) {
+            int sk = (int)(256 / blocks_big);
+            const int cap = pl->ktiles / 8;
+            if (sk > cap) sk = cap;
+            if (sk > 32) sk = 32;
+            if (sk < 1) sk = 1;
+            if (blocks_big * sk >= 128) {
+                tile = n160 ? 8 : 9;
+                auto_sk = sk;
+                if (n160 && sk == 2 && pl->ktiles < 64) { tile = 6; auto_sk = 1; }   // 64x160: the same 256 workgroups without a reduce launch
+            } else {
+                tile = 7;
+                sk = (int)(256 / blocks64);
+                if (sk > cap) sk = cap;
+                if (sk > 32) sk = 32;
+                auto_sk = sk < 1 ? 1 : sk;
+            }
+            ring3 = 1;
+        }
+        else if (short_k && M >= 4096) { tile = (n160 && blocks_big < 256) ? 6 : 9; ring3 = tile == 6; }
         else tile = (n160 && pl->ktiles >= 32) ? (M >= 4096 ? 6 : 3) : 7;
-        if (tile == 7 && M <= 2048) ring3 = 1;    // lone workgroup per CU: a 3-deep ring hides the memory round trip (8 waves: short DMA issue)
+        if (tile == 7 && blocks64 <= 256) ring3 = 1;
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
     if (d->tile == 0 && tile != 5) {
@@ -996,16 +1020,19 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     if (sk <= 0) {
         sk = 1;
         const bool small_tile = kTiles[tile].mf * kTiles[tile].wm <= 4;     // 64-row tiles
-        if (!d->geglu && small_tile && blocks < 96 && pl->ktiles >= 16) {
+        if (auto_sk) {
+            sk = auto_sk;
+        } else if (!d->geglu && small_tile && blocks < 96 && pl->ktiles >= 10) {
             // measured (tools/bench_small.py): with the 3-deep ring a short K loop is cheaper than a split + reduce launch
-            sk = (int)((256 + blocks - 1) / blocks);
-            const int max_by_k = pl->ktiles / 5;
+            // unless the grid is tiny (M = 128)
+            sk = (int)((160 + blocks - 1) / blocks);
+            const int max_by_k = pl->ktiles / (blocks >= 64 ? 16 : 5);
             if (sk > max_by_k) sk = max_by_k;
             if (sk > 32) sk = 32;
             if (sk < 1) sk = 1;
         } else if (!d->geglu && !small_tile && blocks < 192 && pl->ktiles >= 10) {
             sk = (int)((384 + blocks - 1) / blocks);
-            const int max_by_k = pl->ktiles / (kTiles[tile].mf * kTiles[tile].wm <= 4 ? 5 : 8);   // K-steps per split: >= 5 (64-row) / 8 (128-row)
+            const int max_by_k = pl->ktiles / 8;
             if (sk > max_by_k) sk = max_by_k;
             if (sk > 32) sk = 32;
             if (sk < 1) sk = 1;

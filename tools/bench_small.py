@@ -16,10 +16,10 @@ for (m, n, k) in shapes:
     res = torch.randn(m, n, device=dev).to(eng.tdt)
     out = torch.empty(m, n, dtype=eng.tdt, device=dev)
     line = []
-    for tile, sk in ((7, 1), (17, 1), (9, 1), (19, 1), (7, 2), (17, 2), (7, 4), (17, 4), (0, 0)):
-        if n % 160 and tile in (1, 3, 8):
+    for tile, sk in ((0, 0), (7, 1), (17, 1), (9, 1), (19, 1), (16, 1), (8, 1), (18, 1), (17, 2), (19, 2), (18, 2), (17, 4), (18, 3), (18, 4), (18, 6), (17, 8)):
+        if n % 160 and tile % 10 in (1, 3, 6, 8):
             continue
-        if sk > 1 and k // 64 < 2 * sk:
+        if sk > 1 and k // 64 < 5 * sk:
             continue
         def run(i):
             eng.gemm([(x, k, 1, 1, 1, 0)], ws[i % nbuf], n, m, 1, 1, out=out, residual=res, split_k=sk, tile=tile)
