@@ -72,7 +72,7 @@ def load() -> C.CDLL:
         "idb_pack_matrix": (C.c_int, [vp, vp, i64, i64, i32, i32, vp]),
         "idb_lora_merge": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, i32, vp]),
         "idb_groupnorm_workspace_bytes": (sz, [i32, i32, i32]),
-        "idb_groupnorm": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp, sz, vp]),
+        "idb_groupnorm": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp, sz, vp, i32, vp]),
         "idb_layernorm": (C.c_int, [vp, vp, i64, i32, f32, vp, vp, i32, vp]),
         "idb_attention": (C.c_int, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp]),
         "idb_embed_tokens": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

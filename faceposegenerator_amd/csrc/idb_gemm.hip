@@ -887,10 +887,11 @@ __global__ __launch_bounds__(256) void idb_splitk_reduce_kernel(const float* __r
 namespace {
 
 struct TileCfg { int mf, nf, wm; };   // tile = (16*mf*wm) x (32*nf), 128*wm threads
-const TileCfg kTiles[] = {{0, 0, 2}, {4, 5, 2}, {4, 4, 2}, {2, 5, 2}, {2, 4, 2}, {4, 1, 2},
+const TileCfg kTiles[] = {{0, 0, 2}, {4, 5, 2}, {4, 4, 2}, {2, 5, 2}, {1, 2, 4}, {4, 1, 2},
                           {1, 5, 4}, {1, 4, 4}, {2, 5, 4}, {2, 4, 4}};   // index = desc.tile % 10
-// desc.tile = id + 10 * variant.  ids 6-9 have 8 waves per workgroup (2-stage ring only): 6 = 64x160, 7 = 64x128,
-// 8 = 128x160, 9 = 128x128 — the same tiles as 3/4/1/2 with half the LDS-DMA instructions per wave and K-step
+// desc.tile = id + 10 * variant.  ids 4 and 6-9 have 8 waves per workgroup (2- or 3-stage ring): 4 = 64x64, 6 = 64x160,
+// 7 = 64x128, 8 = 128x160, 9 = 128x128 — 6-9 are the tiles 3/-/1/2 with half the LDS-DMA instructions per wave and K-step;
+// 4 exists to put more workgroups on the chip for the smallest batch-1 projections (M = 512, N = 1280: 160 instead of 80)
 // (a 256x160 tile with 8 waves was measured 3-8 % slower than 128x160 with two workgroups per CU and is not kept).
 constexpr int kNumTiles = 9;
 
@@ -947,7 +948,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     int tile = d->tile % 10, ring3 = d->tile / 10;     // ring3: 0 -> 2-stage, 1 -> 3-stage, 2 -> 4-stage LDS ring
     // ring3: 0 -> 2-stage LDS-DMA ring, 1 -> 3-stage, 2 -> 4-stage, 3 -> register-staged double buffer, 4 -> persistent (plain matrices)
     IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 4 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
-                    !(ring3 == 4 && tile > 2) && !(ring3 > 1 && tile >= 6), "idb_gemm: tile id out of range");
+                    !(ring3 == 4 && tile > 2) && !(ring3 > 1 && (tile >= 6 || tile == 4)), "idb_gemm: tile id out of range");
     const bool plain = d->nsrc == 1 && d->src[0].taps == 1 && d->src[0].in_h == 1 && d->src[0].in_w == 1;
     const bool pl_ok = plain && d->split_k <= 1 && d->out_dtype == d->dtype && (d->geglu ? d->n / 2 : d->n) % 4 == 0 &&
                        d->out_ld % 4 == 0 && M * d->out_ld * 2 < (1LL << 31);
@@ -994,6 +995,8 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         else if (short_k && M >= 4096) { tile = (n160 && blocks_big < 256) ? 6 : 9; ring3 = tile == 6; }
         else tile = (n160 && pl->ktiles >= 32) ? (M >= 4096 ? 6 : 3) : 7;
         if (tile == 7 && blocks64 <= 256) ring3 = 1;
+        static const int env_ab = [] { const char* e = getenv("IDB_GEMM_PLAN_AB"); return e ? atoi(e) : 0; }();   // A/B switches for measurements
+        if (tile == 7 && blocks64 <= 160 && !d->geglu && !(env_ab & 1)) tile = 4;   // 64x64: twice the workgroups (m=512 n=1280 k=1280: 12.6 -> 9.9 us)
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
     if (d->tile == 0 && tile != 5) {
@@ -1112,11 +1115,11 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 1: rc = launch_tile<T, 4, 5, 2>(p, pl, st); break;
         case 2: rc = launch_tile<T, 4, 4, 2>(p, pl, st); break;
         case 3: rc = launch_tile<T, 2, 5, 2>(p, pl, st); break;
-        case 4: rc = launch_tile<T, 2, 4, 2>(p, pl, st); break;
+        case 4: rc = launch_tile<T, 1, 2, 2, 4>(p, pl, st); break;
         case 11: rc = launch_tile<T, 4, 5, 3>(p, pl, st); break;
         case 12: rc = launch_tile<T, 4, 4, 3>(p, pl, st); break;
         case 13: rc = launch_tile<T, 2, 5, 3>(p, pl, st); break;
-        case 14: rc = launch_tile<T, 2, 4, 3>(p, pl, st); break;
+        case 14: rc = launch_tile<T, 1, 2, 3, 4>(p, pl, st); break;
         case 6: rc = launch_tile<T, 1, 5, 2, 4>(p, pl, st); break;
         case 7: rc = launch_tile<T, 1, 4, 2, 4>(p, pl, st); break;
         case 8: rc = launch_tile<T, 2, 5, 2, 4>(p, pl, st); break;
@@ -1130,12 +1133,10 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 31: rc = launch_tile_rs<T, 4, 5>(p, pl, st); break;
         case 32: rc = launch_tile_rs<T, 4, 4>(p, pl, st); break;
         case 33: rc = launch_tile_rs<T, 2, 5>(p, pl, st); break;
-        case 34: rc = launch_tile_rs<T, 2, 4>(p, pl, st); break;
         case 35: rc = launch_tile_rs<T, 4, 1>(p, pl, st); break;
         case 21: rc = launch_tile<T, 4, 5, 4>(p, pl, st); break;
         case 22: rc = launch_tile<T, 4, 4, 4>(p, pl, st); break;
         case 23: rc = launch_tile<T, 2, 5, 4>(p, pl, st); break;
-        case 24: rc = launch_tile<T, 2, 4, 4>(p, pl, st); break;
         default: rc = launch_tile<T, 4, 1, 2>(p, pl, st); break;
     }
     if (rc != IDB_OK || pl.splitk == 1 || (d->flags & 1) || p.counters) return rc;

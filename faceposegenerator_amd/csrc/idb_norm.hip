@@ -180,30 +180,39 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* x0, const
     }
 }
 
-// Fused single-launch GroupNorm for small feature maps: one workgroup per (sample, channel slice) keeps its whole
-// slice (HW pixels x SW channels, <= GN_FUSED_MAXIT vectors per thread) in registers: ONE read of the tensor, group
-// statistics through LDS (same fixed-order trees as the two-pass kernels), apply, one write.  Halves the launches of the
-// 32x32 / 16x16 / 8x8 levels, where the two-pass form is launch-latency bound.
-constexpr int GN_FUSED_MAXIT = 24;
+// Single-launch GroupNorm for grids that are co-resident on the chip (the whole batch-1 UNet): each workgroup keeps its
+// (pixel chunk x channel slice) in registers, publishes its partial {sum, sumsq} per group, waits until the other pixel
+// chunks of its (sample, slice) have published theirs, then normalises from registers: ONE read of the tensor, one launch
+// (the two-pass form costs 5.4 + 6.2 us per layer at batch 1, mostly launch ramp and memory round trips).
+// Hand-off protocol (MI355X_MICROARCH.md, "inter-workgroup visibility"): partials are stored with agent-scope relaxed
+// atomic stores (sc1), every storing wave drains vmcnt, workgroup barrier, ONE lane adds to the agent-scope arrival
+// counter; the same lane polls the counter with agent-scope relaxed loads, joins a workgroup barrier, and every wave then
+// reads the partials with agent-scope relaxed loads (sc1: never served from this CU's L1).  Summation order is fixed
+// (chunk index), so results do not depend on arrival order.  The last workgroup to leave resets both counters, so the
+// counter array stays zero between launches.  The poll is bounded: the host only takes this path for grids of at most
+// GN_SYNC_MAXBLOCKS workgroups (all resident at once), and a poll that still runs out gives up rather than hanging.
+constexpr int GN_SYNC_MAXIT = 4;
+constexpr int GN_SYNC_MAXBLOCKS = 1024;
 
 template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_fused_kernel(const T* x0, const T* x1, GnGeom g, const float* gamma,
-                                                              const float* beta, float eps, int silu, T* out) {
+__global__ __launch_bounds__(GN_THREADS) void gn_sync_kernel(const T* x0, const T* x1, GnGeom g, float* partial, int* counters,
+                                                             const float* gamma, const float* beta, float eps, int silu, T* out) {
     __shared__ float part[GN_THREADS][GN_GSLOT][2];
     __shared__ float gmean[64], grstd[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = blockIdx.x, b = blockIdx.y;
+    const int chunk = blockIdx.x, slice = blockIdx.y, b = blockIdx.z;
     const int col = tid % g.cols, row = tid / g.cols;
     const int c = slice * g.SW + col * 8;
+    const int p0 = chunk * g.chunk_len, p1 = min(p0 + g.chunk_len, g.HW);
     const bool active = row < g.PR;
-    typename Op<T>::v8 keep[GN_FUSED_MAXIT];
+    typename Op<T>::v8 keep[GN_SYNC_MAXIT];
     float s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
 #pragma unroll
-    for (int it = 0; it < GN_FUSED_MAXIT; ++it) {
-        const int p = row + it * g.PR;
-        if (active && p < g.HW) {
+    for (int it = 0; it < GN_SYNC_MAXIT; ++it) {
+        const int p = p0 + row + it * g.PR;
+        if (active && p < p1) {
             const long long pix = (long long)b * g.HW + p;
             if (c < g.C0) keep[it] = *(const typename Op<T>::v8*)(x0 + pix * g.C0 + c);
             else keep[it] = *(const typename Op<T>::v8*)(x1 + pix * g.C1 + (c - g.C0));
@@ -236,8 +245,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_fused_kernel(const T* x0, const
     }
     __syncthreads();
     const int nact = g.cols * g.PR;
+    const int slice_g0 = slice * g.gps;
     for (int gl = wave; gl < g.gps; gl += GN_THREADS / 64) {
-        const int ga = slice * g.gps + gl;
+        const int ga = slice_g0 + gl;
         float a = 0.f, q = 0.f;
         for (int t = lane; t < nact; t += 64) {
             const int tc = slice * g.SW + (t % g.cols) * 8;
@@ -250,28 +260,72 @@ __global__ __launch_bounds__(GN_THREADS) void gn_fused_kernel(const T* x0, const
         a = wave_sum(a);
         q = wave_sum(q);
         if (lane == 0) {
-            const double cnt = (double)g.HW * g.cpg;
-            const double mean = (double)a / cnt;
-            double var = (double)q / cnt - mean * mean;
-            if (var < 0.0) var = 0.0;
-            gmean[gl] = (float)mean;
-            grstd[gl] = (float)(1.0 / sqrt(var + (double)eps));
+            float* dst = partial + (((long long)b * g.nchunks + chunk) * g.groups + ga) * 2;
+            __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    int* cnt = counters + ((long long)b * g.nslices + slice) * 2;
+    if (g.nchunks > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.nchunks && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();
+    {
+        const int gl = tid >> 3, sub = tid & 7;
+        for (int g0 = 0; g0 < g.gps; g0 += GN_THREADS / 8) {
+            const int gi = g0 + gl;
+            float a = 0.f, q = 0.f;
+            if (gi < g.gps) {
+                const int ga = slice_g0 + gi;
+                for (int ch = sub; ch < g.nchunks; ch += 8) {
+                    float* src = partial + (((long long)b * g.nchunks + ch) * g.groups + ga) * 2;
+                    a += __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if (gi < g.gps && sub == 0) {
+                const double cnt_el = (double)g.HW * g.cpg;
+                const double mean = (double)a / cnt_el;
+                double var = (double)q / cnt_el - mean * mean;
+                if (var < 0.0) var = 0.0;
+                gmean[gi] = (float)mean;
+                grstd[gi] = (float)(1.0 / sqrt(var + (double)eps));
+            }
+        }
+    }
+    __syncthreads();
+    if (g.nchunks > 1 && tid == 0) {
+        // departures: the partials of this launch have been read by this workgroup; the last one to leave re-arms the pair
+        if (__hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.nchunks - 1) {
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (!active) return;
     float ks[8], kh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int gi = (c + e) / g.cpg - slice * g.gps;
+        const int gi = (c + e) / g.cpg - slice_g0;
         const float k = grstd[gi] * gamma[c + e];
         ks[e] = k;
         kh[e] = beta[c + e] - gmean[gi] * k;
     }
 #pragma unroll
-    for (int it = 0; it < GN_FUSED_MAXIT; ++it) {
-        const int p = row + it * g.PR;
-        if (p < g.HW) {
+    for (int it = 0; it < GN_SYNC_MAXIT; ++it) {
+        const int p = p0 + row + it * g.PR;
+        if (p < p1) {
             typename Op<T>::v8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -377,22 +431,25 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int cols) {
 
 template <typename T>
 int run_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
-                  const float* gamma, const float* beta, int silu, void* out, void* ws, hipStream_t st) {
+                  const float* gamma, const float* beta, int silu, void* out, void* ws, int* sync, int sync_len, hipStream_t st) {
+    GnGeom g = gn_geometry(c0, c1, batch, hw, groups);
     {
-        // small feature maps: one launch, slice of lcm(cpg, 8) channels per workgroup, whole slice in registers
-        GnGeom f = gn_geometry(c0, c1, batch, hw, groups);
-        int sw = f.cpg / gn_gcd(f.cpg, 8) * 8;
-        f.SW = sw; f.cols = sw / 8; f.PR = GN_THREADS / f.cols; f.nslices = f.C / sw; f.gps = sw / f.cpg;
-        // measured: no gain over the two-pass form (batch 1: 5.00 vs 5.07 images/s) -> opt-in only
-        static const int env_fused = [] { const char* e = getenv("IDB_GN_FUSED"); return e ? atoi(e) : 0; }();
-        if (env_fused && (hw + f.PR - 1) / f.PR <= GN_FUSED_MAXIT && f.gps <= 64 && (long long)batch * f.nslices >= 16) {
-            hipLaunchKernelGGL((gn_fused_kernel<T>), dim3(f.nslices, batch), dim3(GN_THREADS), 0, st, (const T*)x0, (const T*)x1, f,
-                               gamma, beta, eps, silu, (T*)out);
-            IDB_CHECK_LAUNCH("idb_groupnorm(fused)");
+        // single launch when the caller passes hand-off counters and every workgroup of the grid is resident at once (see
+        // gn_sync_kernel).  Measured in the sampling loop (batch 1): 5.74 images/s against 6.04 for the two-launch form —
+        // the hand-off is four dependent agent-scope round trips (publish, arrive, poll, read partials), dearer on this
+        // chip than a second launch; the engine therefore passes no counters unless IDB_GN_SYNC=1.
+        GnGeom f = g;
+        f.nchunks = (hw + GN_SYNC_MAXIT * f.PR - 1) / (GN_SYNC_MAXIT * f.PR);
+        f.chunk_len = (hw + f.nchunks - 1) / f.nchunks;
+        const long long blocks = (long long)f.nchunks * f.nslices * batch;
+        if (sync && f.nchunks <= GN_MAXCHUNKS && blocks <= GN_SYNC_MAXBLOCKS && 2LL * batch * f.nslices <= sync_len &&
+            (f.chunk_len + f.PR - 1) / f.PR <= GN_SYNC_MAXIT) {
+            hipLaunchKernelGGL((gn_sync_kernel<T>), dim3(f.nchunks, f.nslices, batch), dim3(GN_THREADS), 0, st, (const T*)x0,
+                               (const T*)x1, f, (float*)ws, sync, gamma, beta, eps, silu, (T*)out);
+            IDB_CHECK_LAUNCH("idb_groupnorm(sync)");
             return IDB_OK;
         }
     }
-    const GnGeom g = gn_geometry(c0, c1, batch, hw, groups);
     hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(g.nchunks, g.nslices, batch), dim3(GN_THREADS), 0, st, (const T*)x0,
                        (const T*)x1, g, (float*)ws);
     IDB_CHECK_LAUNCH("idb_groupnorm(stats)");
@@ -415,7 +472,8 @@ extern "C" size_t idb_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32
 
 extern "C" int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw,
                              int32_t groups, float eps, const float* gamma, const float* beta, int32_t silu, void* out,
-                             int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+                             int32_t dtype, void* workspace, size_t workspace_bytes, int32_t* sync, int32_t sync_len,
+                             void* stream) {
     IDB_REQUIRE(idb_is_operand_dtype(dtype), "idb_groupnorm: dtype must be bf16/f16");
     IDB_REQUIRE(x0 && out && gamma && beta && idb_aligned16(x0) && idb_aligned16(out), "idb_groupnorm: null/unaligned pointer");
     IDB_REQUIRE(batch > 0 && hw > 0 && groups > 0 && c0 > 0 && c1 >= 0, "idb_groupnorm: bad dims");
@@ -431,10 +489,11 @@ extern "C" int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t
     }
     const size_t need = idb_groupnorm_workspace_bytes(batch, hw, groups);
     IDB_REQUIRE(workspace && workspace_bytes >= need, "idb_groupnorm: workspace too small (%zu < %zu)", workspace_bytes, need);
+    IDB_REQUIRE(!sync || (sync_len > 0 && ((uintptr_t)sync & 3) == 0), "idb_groupnorm: bad sync counter array");
     hipStream_t st = (hipStream_t)stream;
     return dtype == IDB_BF16
-               ? run_groupnorm<__bf16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out, workspace, st)
-               : run_groupnorm<_Float16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out, workspace, st);
+               ? run_groupnorm<__bf16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out, workspace, sync, sync_len, st)
+               : run_groupnorm<_Float16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out, workspace, sync, sync_len, st);
 }
 
 extern "C" int idb_layernorm(const void* x, void* out, int64_t rows, int32_t c, float eps, const float* gamma,

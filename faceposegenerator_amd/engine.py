@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -110,6 +111,8 @@ class HipEngine:
         self._ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
         self._gn_ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         self._counters = torch.zeros(1 << 16, dtype=torch.int32, device=self.device)   # split-K tickets (self-resetting)
+        # GroupNorm single-launch hand-off counters (self-resetting); opt-in: measured slower than two launches (idb_norm.hip)
+        self._gn_sync = torch.zeros(1 << 14, dtype=torch.int32, device=self.device) if os.environ.get("IDB_GN_SYNC") == "1" else None
         self.w: Dict[str, torch.Tensor] = {}
         self.master: Dict[str, torch.Tensor] = {}
         self.tproj_off: Dict[str, int] = {}
@@ -372,7 +375,8 @@ class HipEngine:
             self._gn_ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
         L.check(self.lib.idb_groupnorm(x0.data_ptr(), c0, _ptr(x1), c1, batch, hw, groups, eps, gamma.data_ptr(),
                                        beta.data_ptr(), int(silu), out.data_ptr(), self.dt, self._gn_ws.data_ptr(),
-                                       self._gn_ws.numel(), _stream()), "idb_groupnorm")
+                                       self._gn_ws.numel(), _ptr(self._gn_sync), 0 if self._gn_sync is None else self._gn_sync.numel(),
+                                       _stream()), "idb_groupnorm")
         return out
 
     def layernorm(self, x, rows, c, gamma, beta) -> torch.Tensor:

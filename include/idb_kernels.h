@@ -113,12 +113,18 @@ int idb_lora_merge(const float* w, const float* lora_a, const float* lora_b, voi
  * Replaces nn.GroupNorm(32, C) (+ SiLU) of ResnetBlock2D / Transformer2DModel.norm / conv_norm_out
  * and nn.LayerNorm(C) x3 of BasicTransformerBlock.
  * GroupNorm input may be the channel-concatenation of two NHWC tensors (skip connections); the
- * output is one dense [B][HW][C0+C1] tensor.  Statistics are fp32, deterministic (no atomics).
+ * output is one dense [B][HW][C0+C1] tensor.  Statistics are fp32, deterministic (fixed summation
+ * order; no float atomics).
+ * sync: optional array of sync_len int32 counters that is ZERO on first use (the kernel leaves it
+ * zero): when given, and the whole grid is resident on the chip at once (small batches), the two
+ * passes run as ONE launch whose workgroups hand their partial sums over through these counters;
+ * NULL selects the two-launch form.  One array may serve every call on the same stream.
  * ------------------------------------------------------------------------------------------ */
 size_t idb_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups);
 int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw,
                   int32_t groups, float eps, const float* gamma, const float* beta, int32_t silu,
-                  void* out, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+                  void* out, int32_t dtype, void* workspace, size_t workspace_bytes, int32_t* sync,
+                  int32_t sync_len, void* stream);
 int idb_layernorm(const void* x, void* out, int64_t rows, int32_t c, float eps, const float* gamma,
                   const float* beta, int32_t dtype, void* stream);
 
