@@ -846,6 +846,11 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
 }
 
 // Split-K tail: sum the fp32 slabs and apply the same epilogue (bias, per-sample bias, residual).
+// VEC = 4: one thread owns out[m][n .. n+3]; every load of the thread — residual, biases, then the slabs in batches of 8 —
+// is issued unconditionally (clamped slab index, masked in registers) so that the memory round trips overlap: a load inside
+// a data-dependent loop or branch gets an s_waitcnt vmcnt(0) right behind it, and with 8-30 slabs the first version of this
+// kernel spent its time in that many dependent round trips.  Slabs are added in ascending split order (deterministic, and
+// bit-identical to the in-kernel reduce).  VEC = 1 is the scalar fallback for odd widths / unaligned residuals.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void idb_splitk_reduce_kernel(const float* __restrict__ partial, int splitk,
                                                                 int M, int N, int HW, float scale,
@@ -856,28 +861,50 @@ __global__ __launch_bounds__(256) void idb_splitk_reduce_kernel(const float* __r
     if (idx >= total) return;
     const long long e0 = idx * VEC;
     const int m = (int)(e0 / N), n = (int)(e0 - (long long)m * N);
-    float v[VEC];
+    if constexpr (VEC == 4) {
+        using V4 = typename Op<T>::v4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        V4 r4;
+        f32x4 bi = zero, sbv = zero;
+        if (res) r4 = *(const V4*)(res + (long long)m * out_ld + n);          // uniform conditions: no divergence, and the
+        if (bias) bi = *(const f32x4*)(bias + n);                                // waits for these sit behind the slab loads
+        if (sbias) sbv = *(const f32x4*)(sbias + (long long)(m / HW) * sbias_ld + n);
+        const float* src = partial + (long long)m * N + n;
+        const long long slab = (long long)M * N;
+        f32x4 v = zero;
+        for (int z0 = 0; z0 < splitk; z0 += 8) {
+            f32x4 t[8];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
-    for (int z = 0; z < splitk; ++z) {
-        const float* src = partial + ((long long)z * M + m) * N + n;
-        if constexpr (VEC == 4) {
-            const f32x4 t = *(const f32x4*)src;
+            for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(src + (long long)min(z0 + u, splitk - 1) * slab);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += t[e];
-        } else {
-            v[0] += src[0];
+            for (int u = 0; u < 8; ++u) {
+                const bool in = z0 + u < splitk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += in ? t[u][e] : 0.f;
+            }
         }
-    }
-    const float* sb = sbias ? sbias + (long long)(m / HW) * sbias_ld : nullptr;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        v[e] *= scale;
-        if (bias) v[e] += bias[n + e];
-        if (sb) v[e] += sb[n + e];
-        if (res) v[e] += to_f32<T>(res[(long long)m * out_ld + n + e]);
-        if (out_f32) ((float*)out)[(long long)m * out_ld + n + e] = v[e];
-        else ((T*)out)[(long long)m * out_ld + n + e] = from_f32<T>(v[e]);
+        for (int e = 0; e < 4; ++e) {
+            v[e] *= scale;
+            if (bias) v[e] += bi[e];
+            if (sbias) v[e] += sbv[e];
+            if (res) v[e] += to_f32<T>(r4[e]);
+        }
+        if (out_f32) {
+            *(f32x4*)((float*)out + (long long)m * out_ld + n) = v;
+        } else {
+            V4 o = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+            *(V4*)((T*)out + (long long)m * out_ld + n) = o;
+        }
+    } else {
+        float v = 0.f;
+        for (int z = 0; z < splitk; ++z) v += partial[((long long)z * M + m) * N + n];
+        v *= scale;
+        if (bias) v += bias[n];
+        if (sbias) v += sbias[(long long)(m / HW) * sbias_ld + n];
+        if (res) v += to_f32<T>(res[(long long)m * out_ld + n]);
+        if (out_f32) ((float*)out)[(long long)m * out_ld + n] = v;
+        else ((T*)out)[(long long)m * out_ld + n] = from_f32<T>(v);
     }
 }
 
@@ -1140,7 +1167,10 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         default: rc = launch_tile<T, 4, 1, 2>(p, pl, st); break;
     }
     if (rc != IDB_OK || pl.splitk == 1 || (d->flags & 1) || p.counters) return rc;
-    const int vec = (d->n % 4 == 0) ? 4 : 1;
+    const bool vec_ok = d->n % 4 == 0 && d->out_ld % 4 == 0 && idb_aligned16(p.partial) && (!p.bias || idb_aligned16(p.bias)) &&
+                        (!p.sbias || (idb_aligned16(p.sbias) && p.sbias_ld % 4 == 0)) && (!p.res || ((uintptr_t)p.res & 7) == 0) &&
+                        ((uintptr_t)p.out & 15) == 0;
+    const int vec = vec_ok ? 4 : 1;
     const long long total = (long long)pl.M * d->n / vec;
     const int blocks = (int)((total + 255) / 256);
     if (vec == 4)

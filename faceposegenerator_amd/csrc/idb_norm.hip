@@ -39,13 +39,15 @@ inline GnGeom gn_geometry(int c0, int c1, int batch, int hw, int groups) {
     return g;
 }
 
+// Loads are issued unconditionally from clamped addresses and in batches (GN_BATCH per thread) so that a thread has
+// several 16-byte loads in flight: a load inside a divergent branch or a data-dependent loop gets an s_waitcnt vmcnt(0)
+// right behind it, which serialises the memory round trips — at batch 1 these kernels are latency-bound, not HBM-bound.
+constexpr int GN_BATCH = 4;
+
 template <typename T>
-__device__ __forceinline__ void gn_load8(const T* x0, const T* x1, const GnGeom& g, long long pix, int c, float* v) {
-    typename Op<T>::v8 raw;
-    if (c < g.C0) raw = *(const typename Op<T>::v8*)(x0 + pix * g.C0 + c);
-    else raw = *(const typename Op<T>::v8*)(x1 + pix * g.C1 + (c - g.C0));
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = to_f32<T>(raw[e]);
+__device__ __forceinline__ typename Op<T>::v8 gn_load_raw(const T* x0, const T* x1, const GnGeom& g, long long pix, int c) {
+    const T* src = c < g.C0 ? x0 + pix * g.C0 + c : x1 + pix * g.C1 + (c - g.C0);      // address select, no branch
+    return *(const typename Op<T>::v8*)src;
 }
 
 // pass 1: partial {sum, sumsq} per (sample, pixel chunk, group); deterministic (fixed-order LDS + shuffle trees)
@@ -61,13 +63,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* x0, const
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
     if (row < g.PR) {
-        for (int p = p0 + row; p < p1; p += g.PR) {
-            float v[8];
-            gn_load8<T>(x0, x1, g, (long long)b * g.HW + p, c, v);
+        for (int pb = p0 + row; pb < p1; pb += GN_BATCH * g.PR) {
+            typename Op<T>::v8 raw[GN_BATCH];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                s[e] += v[e];
-                ss[e] += v[e] * v[e];
+            for (int u = 0; u < GN_BATCH; ++u)
+                raw[u] = gn_load_raw<T>(x0, x1, g, (long long)b * g.HW + min(pb + u * g.PR, p1 - 1), c);
+#pragma unroll
+            for (int u = 0; u < GN_BATCH; ++u) {
+                if (pb + u * g.PR < p1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = to_f32<T>(raw[u][e]);
+                        s[e] += v;
+                        ss[e] += v * v;
+                    }
+                }
             }
         }
     }
@@ -123,18 +133,32 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* x0, const
     __shared__ float gmean[64], grstd[64];
     const int tid = threadIdx.x;
     const int slice = blockIdx.y, b = blockIdx.z;
-    // group statistics of this slice: 8 lanes per group sum the pixel-chunk partials, then a shuffle tree
+    const int col = tid % g.cols, row = tid / g.cols;
+    const int c = slice * g.SW + col * 8;
+    const bool active = row < g.PR;
+    // affine parameters of this thread's 8 channels: requested first so that they travel with the partial sums
+    const int cl = active ? c : 0;
+    const f32x4 ga0 = *(const f32x4*)(gamma + cl), ga1 = *(const f32x4*)(gamma + cl + 4);
+    const f32x4 be0 = *(const f32x4*)(beta + cl), be1 = *(const f32x4*)(beta + cl + 4);
+    // group statistics of this slice: 8 lanes per group sum the pixel-chunk partials (<= 8 each, all loads in flight
+    // at once), then a shuffle tree
     {
         const int gl = tid >> 3, sub = tid & 7;
         for (int g0 = 0; g0 < g.gps; g0 += GN_THREADS / 8) {
             const int gi = g0 + gl;
+            const int ga = slice * g.gps + min(gi, g.gps - 1);
+            f32x2 pv[GN_MAXCHUNKS / 8];
+#pragma unroll
+            for (int u = 0; u < GN_MAXCHUNKS / 8; ++u) {
+                const int ch = min(sub + 8 * u, g.nchunks - 1);
+                pv[u] = *(const f32x2*)(partial + (((long long)b * g.nchunks + ch) * g.groups + ga) * 2);
+            }
             float a = 0.f, q = 0.f;
-            if (gi < g.gps) {
-                const int ga = slice * g.gps + gi;
-                for (int ch = sub; ch < g.nchunks; ch += 8) {
-                    const float* src = partial + (((long long)b * g.nchunks + ch) * g.groups + ga) * 2;
-                    a += src[0];
-                    q += src[1];
+#pragma unroll
+            for (int u = 0; u < GN_MAXCHUNKS / 8; ++u) {
+                if (gi < g.gps && sub + 8 * u < g.nchunks) {
+                    a += pv[u][0];
+                    q += pv[u][1];
                 }
             }
 #pragma unroll
@@ -153,30 +177,35 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* x0, const
         }
     }
     __syncthreads();
-    const int col = tid % g.cols, row = tid / g.cols;
-    if (row >= g.PR) return;
-    const int c = slice * g.SW + col * 8;
+    if (!active) return;
     float ks[8], kh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int gi = (c + e) / g.cpg - slice * g.gps;
-        const float k = grstd[gi] * gamma[c + e];
+        const float k = grstd[gi] * (e < 4 ? ga0[e & 3] : ga1[e & 3]);
         ks[e] = k;
-        kh[e] = beta[c + e] - gmean[gi] * k;
+        kh[e] = (e < 4 ? be0[e & 3] : be1[e & 3]) - gmean[gi] * k;
     }
     const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, g.HW);
-    for (int p = p0 + row; p < p1; p += g.PR) {
-        const long long pix = (long long)b * g.HW + p;
-        float v[8];
-        gn_load8<T>(x0, x1, g, pix, c, v);
-        typename Op<T>::v8 o;
+    for (int pb = p0 + row; pb < p1; pb += GN_BATCH * g.PR) {
+        typename Op<T>::v8 raw[GN_BATCH];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float y = v[e] * ks[e] + kh[e];
-            if (silu) y = silu_f(y);
-            o[e] = from_f32<T>(y);
+        for (int u = 0; u < GN_BATCH; ++u)
+            raw[u] = gn_load_raw<T>(x0, x1, g, (long long)b * g.HW + min(pb + u * g.PR, p1 - 1), c);
+#pragma unroll
+        for (int u = 0; u < GN_BATCH; ++u) {
+            const int p = pb + u * g.PR;
+            if (p < p1) {
+                typename Op<T>::v8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = to_f32<T>(raw[u][e]) * ks[e] + kh[e];
+                    if (silu) y = silu_f(y);
+                    o[e] = from_f32<T>(y);
+                }
+                *(typename Op<T>::v8*)(out + ((long long)b * g.HW + p) * g.C + c) = o;
+            }
         }
-        *(typename Op<T>::v8*)(out + pix * g.C + c) = o;
     }
 }
 
@@ -209,13 +238,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_sync_kernel(const T* x0, const 
     float s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    const int cl = active ? c : slice * g.SW;
+#pragma unroll
+    for (int it = 0; it < GN_SYNC_MAXIT; ++it)
+        keep[it] = gn_load_raw<T>(x0, x1, g, (long long)b * g.HW + min(p0 + row + it * g.PR, p1 - 1), cl);
 #pragma unroll
     for (int it = 0; it < GN_SYNC_MAXIT; ++it) {
-        const int p = p0 + row + it * g.PR;
-        if (active && p < p1) {
-            const long long pix = (long long)b * g.HW + p;
-            if (c < g.C0) keep[it] = *(const typename Op<T>::v8*)(x0 + pix * g.C0 + c);
-            else keep[it] = *(const typename Op<T>::v8*)(x1 + pix * g.C1 + (c - g.C0));
+        if (active && p0 + row + it * g.PR < p1) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = to_f32<T>(keep[it][e]);
@@ -338,37 +367,42 @@ __global__ __launch_bounds__(GN_THREADS) void gn_sync_kernel(const T* x0, const 
     }
 }
 
-// LayerNorm: one wave per row, row held in registers (C <= 1536), exact two-pass variance.
-template <typename T>
+// LayerNorm: one wave per row, row held in registers (C <= 1536 = NCH x 64 lanes x 8), exact two-pass variance.  The row
+// and the affine parameters are requested together, from clamped addresses, so that the kernel is ONE memory round trip.
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* out, long long rows, int C, float eps,
                                                         const float* gamma, const float* beta) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int Ct = C >> 3;
-    float v[3][8];
+    typename Op<T>::v8 raw[NCH];
+    f32x4 g0[NCH], g1[NCH], b0[NCH], b1[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int cc = min(lane + i * 64, Ct - 1);
+        raw[i] = *(const typename Op<T>::v8*)(x + row * C + cc * 8);
+        g0[i] = *(const f32x4*)(gamma + cc * 8);
+        g1[i] = *(const f32x4*)(gamma + cc * 8 + 4);
+        b0[i] = *(const f32x4*)(beta + cc * 8);
+        b1[i] = *(const f32x4*)(beta + cc * 8 + 4);
+    }
+    float v[NCH][8];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int cc = lane + i * 64;
-        if (cc < Ct) {
-            const typename Op<T>::v8 raw = *(const typename Op<T>::v8*)(x + row * C + cc * 8);
+    for (int i = 0; i < NCH; ++i) {
+        const bool in = lane + i * 64 < Ct;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[i][e] = to_f32<T>(raw[e]);
-                sum += v[i][e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        for (int e = 0; e < 8; ++e) {
+            v[i][e] = in ? to_f32<T>(raw[i][e]) : 0.f;
+            sum += v[i][e];
         }
     }
     const float mean = wave_sum(sum) / (float)C;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int cc = lane + i * 64;
-        if (cc < Ct) {
+    for (int i = 0; i < NCH; ++i) {
+        if (lane + i * 64 < Ct) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float d = v[i][e] - mean;
@@ -378,16 +412,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* out, long
     }
     const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int cc = lane + i * 64;
         if (cc < Ct) {
             typename Op<T>::v8 o;
-            const f32x4 g0 = *(const f32x4*)(gamma + cc * 8), g1 = *(const f32x4*)(gamma + cc * 8 + 4);
-            const f32x4 b0 = *(const f32x4*)(beta + cc * 8), b1 = *(const f32x4*)(beta + cc * 8 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[e] = from_f32<T>((v[i][e] - mean) * rstd * g0[e] + b0[e]);
-                o[e + 4] = from_f32<T>((v[i][e + 4] - mean) * rstd * g1[e] + b1[e]);
+                o[e] = from_f32<T>((v[i][e] - mean) * rstd * g0[i][e] + b0[i][e]);
+                o[e + 4] = from_f32<T>((v[i][e + 4] - mean) * rstd * g1[i][e] + b1[i][e]);
             }
             *(typename Op<T>::v8*)(out + row * C + cc * 8) = o;
         }
@@ -435,9 +467,12 @@ int run_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int
     GnGeom g = gn_geometry(c0, c1, batch, hw, groups);
     {
         // single launch when the caller passes hand-off counters and every workgroup of the grid is resident at once (see
-        // gn_sync_kernel).  Measured in the sampling loop (batch 1): 5.74 images/s against 6.04 for the two-launch form —
-        // the hand-off is four dependent agent-scope round trips (publish, arrive, poll, read partials), dearer on this
-        // chip than a second launch; the engine therefore passes no counters unless IDB_GN_SYNC=1.
+        // gn_sync_kernel).  Measured in the sampling loop (batch 1, A/B on one box): 6.05 images/s against 6.28 for the
+        // two-launch form — the hand-off is four dependent agent-scope round trips (publish, arrive, poll, read partials),
+        // dearer on this chip than a second launch (1.8 us floor inside a graph); the engine therefore passes no counters
+        // unless IDB_GN_SYNC=1.  A one-workgroup-per-(sample, slice) form that keeps feature maps up to 32x32 in registers
+        // (one launch, one read) measured equal to the two-launch form (6.285 vs 6.284: 32-64 workgroups cannot pull their
+        // slices faster than 512 can pull them twice) and was dropped.
         GnGeom f = g;
         f.nchunks = (hw + GN_SYNC_MAXIT * f.PR - 1) / (GN_SYNC_MAXIT * f.PR);
         f.chunk_len = (hw + f.nchunks - 1) / f.nchunks;
@@ -475,7 +510,8 @@ extern "C" int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t
                              int32_t dtype, void* workspace, size_t workspace_bytes, int32_t* sync, int32_t sync_len,
                              void* stream) {
     IDB_REQUIRE(idb_is_operand_dtype(dtype), "idb_groupnorm: dtype must be bf16/f16");
-    IDB_REQUIRE(x0 && out && gamma && beta && idb_aligned16(x0) && idb_aligned16(out), "idb_groupnorm: null/unaligned pointer");
+    IDB_REQUIRE(x0 && out && gamma && beta && idb_aligned16(x0) && idb_aligned16(out) && idb_aligned16(gamma) && idb_aligned16(beta),
+                "idb_groupnorm: null/unaligned pointer");
     IDB_REQUIRE(batch > 0 && hw > 0 && groups > 0 && c0 > 0 && c1 >= 0, "idb_groupnorm: bad dims");
     IDB_REQUIRE((c1 == 0) == (x1 == nullptr), "idb_groupnorm: x1/c1 mismatch");
     IDB_REQUIRE(c1 == 0 || idb_aligned16(x1), "idb_groupnorm: x1 unaligned");
@@ -505,12 +541,15 @@ extern "C" int idb_layernorm(const void* x, void* out, int64_t rows, int32_t c, 
     const long long blocks = (rows + 3) / 4;
     IDB_REQUIRE(blocks < (1LL << 31), "idb_layernorm: too many rows");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == IDB_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, st, (const __bf16*)x, (__bf16*)out,
-                           (long long)rows, c, eps, gamma, beta);
-    else
-        hipLaunchKernelGGL((layernorm_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, st, (const _Float16*)x,
-                           (_Float16*)out, (long long)rows, c, eps, gamma, beta);
+    const int nch = (c / 8 + 63) / 64;
+#define IDB_LN_LAUNCH(TT, N) \
+    hipLaunchKernelGGL((layernorm_kernel<TT, N>), dim3((unsigned)blocks), dim3(256), 0, st, (const TT*)x, (TT*)out, (long long)rows, c, eps, gamma, beta)
+    if (dtype == IDB_BF16) {
+        if (nch == 1) IDB_LN_LAUNCH(__bf16, 1); else if (nch == 2) IDB_LN_LAUNCH(__bf16, 2); else IDB_LN_LAUNCH(__bf16, 3);
+    } else {
+        if (nch == 1) IDB_LN_LAUNCH(_Float16, 1); else if (nch == 2) IDB_LN_LAUNCH(_Float16, 2); else IDB_LN_LAUNCH(_Float16, 3);
+    }
+#undef IDB_LN_LAUNCH
     IDB_CHECK_LAUNCH("idb_layernorm");
     return IDB_OK;
 }

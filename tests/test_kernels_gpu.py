@@ -208,7 +208,9 @@ def test_gemm_rejects_bad_args(eng):
 # norms / softmax
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("b,hw,c0,c1,silu,eps", [(2, 256, 64, 0, True, 1e-5), (3, 64, 320, 0, False, 1e-6), (2, 100, 1280, 640, True, 1e-5),
-                                                 (1, 4096, 128, 0, True, 1e-6), (2, 64, 1280, 1280, True, 1e-5), (4, 1024, 640, 320, True, 1e-5)])
+                                                 (1, 4096, 128, 0, True, 1e-6), (2, 64, 1280, 1280, True, 1e-5), (4, 1024, 640, 320, True, 1e-5),
+                                                 (2, 1024, 1280, 640, True, 1e-5), (2, 1024, 640, 0, False, 1e-5), (2, 256, 1280, 0, True, 1e-5),
+                                                 (3, 16, 64, 0, True, 1e-5), (2, 4, 128, 128, False, 1e-6), (2, 1600, 320, 0, True, 1e-5)])
 def test_groupnorm(eng, b, hw, c0, c1, silu, eps):
     x0 = (_rand((b, hw, c0), 30) * 2 + 0.5).to(eng.tdt)
     x1 = (_rand((b, hw, c1), 31) - 1.0).to(eng.tdt) if c1 else None
