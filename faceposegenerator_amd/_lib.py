@@ -24,7 +24,7 @@ EXPORTS = [
     "idb_attention", "idb_embed_tokens", "idb_softmax_rows",
     "idb_timestep_sinusoid", "idb_linear_f32", "idb_conv_in",
     "idb_cfg_ddpm_step", "idb_postprocess",
-    "idb_nhwc_to_nchw_f32", "idb_f32_nhwc_to_nchw", "idb_cast_f32",
+    "idb_nhwc_to_nchw_f32", "idb_f32_nhwc_to_nchw", "idb_cast_f32", "idb_vae_sample",
 ]
 
 
@@ -41,7 +41,7 @@ class GemmDesc(C.Structure):
                 ("sample_bias_ld", C.c_int32), ("residual", C.c_void_p), ("geglu", C.c_int32),
                 ("out", C.c_void_p), ("out_dtype", C.c_int32), ("out_ld", C.c_int32),
                 ("split_k", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float), ("flags", C.c_int32), ("act", C.c_int32),
-                ("counters", C.c_void_p), ("counters_len", C.c_int32)]
+                ("counters", C.c_void_p), ("counters_len", C.c_int32), ("pad_mode", C.c_int32)]
 
 
 class IdbError(RuntimeError):
@@ -85,6 +85,7 @@ def load() -> C.CDLL:
         "idb_nhwc_to_nchw_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
         "idb_f32_nhwc_to_nchw": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "idb_cast_f32": (C.c_int, [vp, vp, i64, i32, vp]),
+        "idb_vae_sample": (C.c_int, [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing

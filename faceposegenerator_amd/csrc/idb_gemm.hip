@@ -30,7 +30,7 @@ struct GemmSrcK {
 
 struct GemmParams {
     GemmSrcK src[IDB_MAX_SRC];
-    int M, N, HW, OW, stride;
+    int M, N, HW, OW, stride, pad;
     unsigned w_row_bytes, w_bytes;
     int ktiles, kt_per_split, splitk;
     const char* w;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
         cur_c = S.C;
         tap_end = S.taps == 9 ? 9 : 5;
         const int t3 = tap / 3;
-        const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
+        const int dy = t3 - p.pad, dx = tap - t3 * 3 - p.pad;
         const int LH = S.H << S.up, LW = S.W << S.up;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_rs(const GemmParams p)
             cur_c = S.C;
             tap_end = S.taps == 9 ? 9 : 5;
             const int t3 = tap / 3;
-            const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
+            const int dy = t3 - p.pad, dx = tap - t3 * 3 - p.pad;
             const int LH = S.H << S.up, LW = S.W << S.up;
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
@@ -932,6 +932,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     IDB_REQUIRE(idb_is_operand_dtype(d->dtype), "idb_gemm: dtype must be bf16 or f16 (got %d)", d->dtype);
     IDB_REQUIRE(d->batch > 0 && d->out_h > 0 && d->out_w > 0 && d->n > 0, "idb_gemm: non-positive dims");
     IDB_REQUIRE(d->stride == 1 || d->stride == 2, "idb_gemm: stride must be 1 or 2");
+    IDB_REQUIRE(d->pad_mode == 0 || (d->pad_mode == 1 && d->stride == 2), "idb_gemm: pad_mode must be 0, or 1 with stride 2");
     IDB_REQUIRE(d->nsrc >= 1 && d->nsrc <= IDB_MAX_SRC, "idb_gemm: nsrc out of range");
     IDB_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == IDB_F32, "idb_gemm: out_dtype must be dtype or f32");
     const long long M = (long long)d->batch * d->out_h * d->out_w;
@@ -1219,6 +1220,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.HW = d->out_h * d->out_w;
     p.OW = d->out_w;
     p.stride = d->stride;
+    p.pad = d->pad_mode == 1 ? 0 : 1;
     p.w_row_bytes = (unsigned)(pl.K * 2);
     p.w_bytes = (unsigned)((long long)d->n * pl.K * 2);
     p.ktiles = pl.ktiles;

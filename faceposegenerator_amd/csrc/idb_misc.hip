@@ -188,6 +188,25 @@ __global__ __launch_bounds__(256) void cfg_ddpm_kernel(const float* __restrict__
 }
 
 // K10
+// DiagonalGaussianDistribution.sample()/.mode() * scaling_factor: moments NHWC [B][HW][2C] -> latents NCHW [B][C][HW]
+__global__ __launch_bounds__(256) void vae_sample_kernel(const float* __restrict__ moments, const float* __restrict__ noise,
+                                                         float scale, float* __restrict__ latents, float* __restrict__ mean_out,
+                                                         float* __restrict__ logvar_out, int batch, int channels, int hw) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;         // NCHW index
+    if (i >= (long long)batch * channels * hw) return;
+    const int p = (int)(i % hw);
+    const int c = (int)((i / hw) % channels);
+    const long long b = i / ((long long)hw * channels);
+    const float* m = moments + (b * hw + p) * (2 * channels);
+    const float mean = m[c];
+    const float logvar = fminf(fmaxf(m[channels + c], -30.f), 20.f);
+    float z = mean;
+    if (noise) z += expf(0.5f * logvar) * noise[i];
+    latents[i] = z * scale;
+    if (mean_out) mean_out[i] = mean;
+    if (logvar_out) logvar_out[i] = logvar;
+}
+
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ x, float* __restrict__ img,
                                                           uint8_t* __restrict__ u8, long long count) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -320,6 +339,15 @@ extern "C" int idb_cfg_ddpm_step(const float* eps, float* latents, const float* 
     hipLaunchKernelGGL(cfg_ddpm_kernel, dim3(blocks_for((long long)batch * channels * hw)), dim3(256), 0, (hipStream_t)stream,
                        eps, latents, noise, coef, x0_out, batch, channels, hw, cfg, prediction_type);
     IDB_CHECK_LAUNCH("idb_cfg_ddpm_step");
+    return IDB_OK;
+}
+
+extern "C" int idb_vae_sample(const float* moments, const float* noise, float scale, float* latents, float* mean_out,
+                              float* logvar_out, int32_t batch, int32_t channels, int32_t hw, void* stream) {
+    IDB_REQUIRE(moments && latents && batch > 0 && channels > 0 && hw > 0, "idb_vae_sample: bad args");
+    hipLaunchKernelGGL(vae_sample_kernel, dim3(blocks_for((long long)batch * channels * hw)), dim3(256), 0, (hipStream_t)stream,
+                       moments, noise, scale, latents, mean_out, logvar_out, batch, channels, hw);
+    IDB_CHECK_LAUNCH("idb_vae_sample");
     return IDB_OK;
 }
 

@@ -313,6 +313,38 @@ class HipEngine:
         w["v.conv_out.w"] = self._pack_conv(sd["decoder.conv_out.weight"])
         w["v.conv_out.b"] = self._f32(sd["decoder.conv_out.bias"])
 
+    def pack_vae_encoder(self, sd: SD) -> None:
+        """AutoencoderKL encoder weights (train_ID-Booth.py:1001): packed on first use — the sampling path never needs them.
+        quant_conv (1x1, 8 -> 8) is folded into conv_out in fp32 (a 1x1 conv after a 3x3 conv is a linear map of its output
+        channels): W'[o] = sum_j Wq[o][j] W[j], b' = Wq b + bq, rounded to the operand dtype once."""
+        w, cfg = self.w, self.vcfg
+        w["ve.conv_in.w"] = self._f32(sd["encoder.conv_in.weight"])
+        w["ve.conv_in.b"] = self._f32(sd["encoder.conv_in.bias"])
+        for blk in S.vae_encoder_blocks(cfg):
+            for name, _, _ in blk["resnets"]:
+                self._pack_resnet(sd, name, False)
+            if blk["down"]:
+                w[blk["down"] + ".w"] = self._pack_conv(sd[blk["down"] + ".weight"])
+                w[blk["down"] + ".b"] = self._f32(sd[blk["down"] + ".bias"])
+        for nm in ("encoder.mid_block.resnets.0", "encoder.mid_block.resnets.1"):
+            self._pack_resnet(sd, nm, False)
+        a = "encoder.mid_block.attentions.0"
+        w[f"{a}.gn.g"] = self._f32(sd[f"{a}.group_norm.weight"])
+        w[f"{a}.gn.b"] = self._f32(sd[f"{a}.group_norm.bias"])
+        for t, short in (("to_q", "q"), ("to_k", "k"), ("to_v", "v"), ("to_out.0", "o")):
+            w[f"{a}.{short}.w"] = self._pack_mat(sd[f"{a}.{t}.weight"])
+            w[f"{a}.{short}.b"] = self._f32(sd[f"{a}.{t}.bias"])
+        w["ve.norm_out.g"] = self._f32(sd["encoder.conv_norm_out.weight"])
+        w["ve.norm_out.b"] = self._f32(sd["encoder.conv_norm_out.bias"])
+        wq = sd["quant_conv.weight"].double().reshape(2 * cfg.latent_channels, 2 * cfg.latent_channels)
+        co = sd["encoder.conv_out.weight"].double()
+        folded = torch.einsum("oj,jikl->oikl", wq, co).float()
+        fb = (wq @ sd["encoder.conv_out.bias"].double() + sd["quant_conv.bias"].double()).float()
+        w["ve.conv_out.w"] = self._pack_conv(folded)
+        w["ve.conv_out.b"] = self._f32(fb)
+        self.has_vae_encoder = True
+        torch.cuda.synchronize(self.device)
+
     # ------------------------------------------------------------------------------------
     # kernel wrappers
     # ------------------------------------------------------------------------------------
@@ -325,7 +357,7 @@ class HipEngine:
 
     def gemm(self, srcs, w: torch.Tensor, n: int, batch: int, oh: int, ow: int, bias=None, sbias=None,
              residual=None, geglu=False, stride=1, out_f32=False, out_scale=0.0, split_k=0, tile=0,
-             out: Optional[torch.Tensor] = None, flags: int = 0, act: int = 0) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, flags: int = 0, act: int = 0, pad_mode: int = 0) -> torch.Tensor:
         """srcs: list of (tensor, channels, taps, in_h, in_w, upsample); sbias: (tensor, elem_offset, ld)."""
         m = batch * oh * ow
         ncols = n // 2 if geglu else n
@@ -343,6 +375,7 @@ class HipEngine:
         d.residual, d.geglu = _ptr(residual), int(geglu)
         d.out, d.out_dtype, d.out_ld = out.data_ptr(), (L.IDB_F32 if out_f32 else self.dt), out.shape[-1]
         d.split_k, d.tile, d.out_scale, d.flags, d.act = split_k, tile, out_scale, flags, act
+        d.pad_mode = pad_mode
         d.counters, d.counters_len = self._counters.data_ptr(), self._counters.numel()
         need = self.lib.idb_gemm_workspace_bytes(C.byref(d))
         ws = self._workspace(need) if need else None
@@ -656,8 +689,8 @@ class HipEngine:
     # ------------------------------------------------------------------------------------
     # VAE decoder (AutoencoderKL.decode -> Decoder.forward)
     # ------------------------------------------------------------------------------------
-    def _vae_attention(self, x, batch, h, w_, c) -> torch.Tensor:
-        W, a = self.w, "decoder.mid_block.attentions.0"
+    def _vae_attention(self, x, batch, h, w_, c, a: str = "decoder.mid_block.attentions.0") -> torch.Tensor:
+        W = self.w
         hw = h * w_
         G = self.vcfg.norm_num_groups
         xn = self.groupnorm(x, c, None, 0, batch, hw, W[f"{a}.gn.g"], W[f"{a}.gn.b"], self.vcfg.norm_eps, False, G)
@@ -715,6 +748,72 @@ class HipEngine:
                         out_f32=True)
         self.arena.free(n)
         return img
+
+    # ------------------------------------------------------------------------------------
+    # VAE encoder (AutoencoderKL.encode -> Encoder.forward + quant_conv; train_ID-Booth.py:1001)
+    # ------------------------------------------------------------------------------------
+    def vae_encode_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        """x fp32 NCHW [B,3,H,W] in [-1,1] -> moments fp32 [B*h*w, 2*latent_channels] (mean channels, then log-variance)."""
+        if not getattr(self, "has_vae_encoder", False):
+            raise RuntimeError("VAE encoder weights are not loaded (pack_vae_encoder)")
+        W, cfg = self.w, self.vcfg
+        B, ic, h, w_ = x.shape
+        G, eps_n = cfg.norm_num_groups, cfg.norm_eps
+        c0 = cfg.block_out_channels[0]
+        cur = self.arena.alloc((B * h * w_, c0), self.tdt)
+        L.check(self.lib.idb_conv_in(x.data_ptr(), W["ve.conv_in.w"].data_ptr(), W["ve.conv_in.b"].data_ptr(), cur.data_ptr(), B, 1,
+                                     ic, h, w_, c0, 1.0, None, None, self.dt, _stream()), "idb_conv_in")
+        ch = c0
+        for blk in S.vae_encoder_blocks(cfg):
+            for name, cin, cout in blk["resnets"]:
+                y = self._resnet(name, cur, cin, None, 0, cout, B, h, w_, None, eps_n, G)
+                self.arena.free(cur)
+                cur, ch = y, cout
+            if blk["down"]:
+                if h % 2 or w_ % 2:
+                    raise ValueError("VAE encoder needs image sides that are multiples of 8")
+                y = self.gemm([(cur, ch, 9, h, w_, 0)], W[blk["down"] + ".w"], ch, B, h // 2, w_ // 2, bias=W[blk["down"] + ".b"],
+                              stride=2, pad_mode=1)
+                self.arena.free(cur)
+                cur = y
+                h, w_ = h // 2, w_ // 2
+        y = self._resnet("encoder.mid_block.resnets.0", cur, ch, None, 0, ch, B, h, w_, None, eps_n, G)
+        self.arena.free(cur)
+        cur = self._vae_attention(y, B, h, w_, ch, "encoder.mid_block.attentions.0")
+        self.arena.free(y)
+        y = self._resnet("encoder.mid_block.resnets.1", cur, ch, None, 0, ch, B, h, w_, None, eps_n, G)
+        self.arena.free(cur)
+        n = self.groupnorm(y, ch, None, 0, B, h * w_, W["ve.norm_out.g"], W["ve.norm_out.b"], eps_n, True, G)
+        self.arena.free(y)
+        mom = self.gemm([(n, ch, 9, h, w_, 0)], W["ve.conv_out.w"], 2 * cfg.latent_channels, B, h, w_, bias=W["ve.conv_out.b"],
+                        out_f32=True)
+        self.arena.free(n)
+        return mom
+
+    def vae_encode(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None, scale: float = 1.0, chunk: int = 4):
+        """``vae.encode(x).latent_dist``: returns (latents, mean, logvar), NCHW fp32.  latents = (mean + std * noise) * scale
+        with noise [B,C,h,w] (``.sample()``) or mean * scale when noise is None (``.mode()``)."""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        B, _, H, Wd = x.shape
+        down = 2 ** (len(self.vcfg.block_out_channels) - 1)
+        if H % down or Wd % down:
+            raise ValueError(f"image sides must be multiples of {down}")
+        h, w_, lc = H // down, Wd // down, self.vcfg.latent_channels
+        lat = torch.empty((B, lc, h, w_), dtype=torch.float32, device=self.device)
+        mean, logvar = torch.empty_like(lat), torch.empty_like(lat)
+        nz = None if noise is None else noise.to(device=self.device, dtype=torch.float32).contiguous()
+        if nz is not None and tuple(nz.shape) != tuple(lat.shape):
+            raise ValueError(f"noise must have shape {tuple(lat.shape)}")
+        for b0 in range(0, B, chunk):
+            self.arena.reset()
+            self._pinned.clear()
+            xb = x[b0:b0 + chunk].contiguous()
+            mom = self.vae_encode_nhwc(xb)
+            L.check(self.lib.idb_vae_sample(mom.data_ptr(), None if nz is None else nz[b0:b0 + chunk].data_ptr(), float(scale),
+                                            lat[b0:b0 + chunk].data_ptr(), mean[b0:b0 + chunk].data_ptr(),
+                                            logvar[b0:b0 + chunk].data_ptr(), xb.shape[0], lc, h * w_, _stream()), "idb_vae_sample")
+            self.arena.free(mom)
+        return lat, mean, logvar
 
     def vae_decode(self, z: torch.Tensor, in_scale: float = 1.0, chunk: int = 4):
         """Returns (raw NCHW fp32 [B,3,H,W])  — the ``vae.decode(z).sample`` API form."""

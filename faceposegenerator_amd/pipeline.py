@@ -40,6 +40,32 @@ class _DecoderOutput:
         self.sample = sample
 
 
+class _LatentDist:
+    """DiagonalGaussianDistribution as the reference uses it: ``vae.encode(x).latent_dist.sample()`` (train_ID-Booth.py:1001)."""
+
+    def __init__(self, engine, image):
+        self._engine, self._image = engine, image
+        _, self.mean, self.logvar = engine.vae_encode(image, None)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator=None):
+        # upstream randn_tensor: a CPU generator draws on the CPU, then the sample moves to the device
+        if generator is not None and generator.device.type == "cpu":
+            noise = torch.randn(self.mean.shape, generator=generator, dtype=torch.float32).to(self.mean.device)
+        else:
+            noise = torch.randn(self.mean.shape, generator=generator, dtype=torch.float32, device=self.mean.device)
+        return self._engine.vae_encode(self._image, noise)[0]
+
+    def mode(self):
+        return self.mean
+
+
+class _EncoderOutput:
+    def __init__(self, latent_dist):
+        self.latent_dist = latent_dist
+
+
 class UNetHandle:
     """``pipe.unet``: callable like UNet2DConditionModel for the kwargs the reference uses."""
 
@@ -67,6 +93,17 @@ class VAEHandle:
         out = self._pipe._engine().vae_decode(z)
         return (out,) if not return_dict else _DecoderOutput(out)
 
+    def encode(self, x, return_dict: bool = True, **kw):
+        """``vae.encode(pixel_values).latent_dist`` (train_ID-Booth.py:1001); x: [B,3,H,W] in [-1,1]."""
+        eng = self._pipe._engine()
+        if not getattr(eng, "has_vae_encoder", False):
+            sd = self._pipe.vae_encoder_state_dict()
+            if sd is None:
+                raise FileNotFoundError("this pipeline was built without VAE encoder weights")
+            eng.pack_vae_encoder(sd)
+        dist = _LatentDist(eng, x)
+        return (dist,) if not return_dict else _EncoderOutput(dist)
+
 
 class StableDiffusionPipeline:
     def __init__(self, unet_config: S.UNetConfig, vae_config: S.VAEConfig, unet_sd, vae_sd,
@@ -91,6 +128,16 @@ class StableDiffusionPipeline:
         self.unet = UNetHandle(self)
         self.vae = VAEHandle(self)
         self.vae_scale_factor = 2 ** (len(vae_config.block_out_channels) - 1)
+        self._vae_encoder = None             # state dict, or a directory to read it from on first vae.encode()
+
+    def vae_encoder_state_dict(self):
+        if isinstance(self._vae_encoder, str):
+            self._vae_encoder = W.load_vae_encoder_weights(self._vae_encoder)
+        return self._vae_encoder
+
+    def set_vae_encoder_weights(self, sd) -> None:
+        """Attach AutoencoderKL encoder weights (``encoder.*``, ``quant_conv.*``) to a pipeline built from state dicts."""
+        self._vae_encoder = sd
 
     # ---- construction -----------------------------------------------------------------
     @classmethod
@@ -107,8 +154,10 @@ class StableDiffusionPipeline:
         if text is not None and os.path.isdir(os.path.join(root, "tokenizer")):
             from transformers import CLIPTokenizer           # host-side string -> ids, as the reference uses it
             tokenizer = CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer"))
-        return cls(ucfg, vcfg, W.load_unet_weights(root), W.load_vae_decoder_weights(root), DDPMScheduler(scfg), torch_dtype,
+        pipe = cls(ucfg, vcfg, W.load_unet_weights(root), W.load_vae_decoder_weights(root), DDPMScheduler(scfg), torch_dtype,
                    text_encoder=text, tokenizer=tokenizer)
+        pipe._vae_encoder = root             # encoder.* / quant_conv.* are read only if vae.encode() is called
+        return pipe
 
     @classmethod
     def from_synthetic(cls, unet_config: S.UNetConfig = S.SD21_UNET, vae_config: S.VAEConfig = S.SD21_VAE,

@@ -335,6 +335,49 @@ def vae_decoder_param_shapes(cfg: VAEConfig = SD21_VAE) -> Dict[str, Shape]:
     return out
 
 
+def vae_encoder_blocks(cfg: VAEConfig = SD21_VAE) -> List[dict]:
+    """diffusers Encoder.down_blocks (DownEncoderBlock2D x4): layers_per_block resnets each, a stride-2 Downsample2D
+    (padding 0 + F.pad (0,1,0,1)) after every block but the last (AutoencoderKL.encode, train_ID-Booth.py:1001)."""
+    blocks, prev = [], cfg.block_out_channels[0]
+    for i, ch in enumerate(cfg.block_out_channels):
+        blk = {"resnets": [], "down": None, "channels": ch}
+        for j in range(cfg.layers_per_block):
+            blk["resnets"].append((f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else ch, ch))
+        if i != len(cfg.block_out_channels) - 1:
+            blk["down"] = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+        blocks.append(blk)
+        prev = ch
+    return blocks
+
+
+def vae_encoder_param_shapes(cfg: VAEConfig = SD21_VAE) -> Dict[str, Shape]:
+    out: Dict[str, Shape] = {}
+    lc, c0, cm = cfg.latent_channels, cfg.block_out_channels[0], cfg.block_out_channels[-1]
+    out["encoder.conv_in.weight"] = (c0, cfg.out_channels, 3, 3)          # in_channels == out_channels == 3 (RGB)
+    out["encoder.conv_in.bias"] = (c0,)
+    for blk in vae_encoder_blocks(cfg):
+        for name, cin, cout in blk["resnets"]:
+            _resnet(name, cin, cout, None, out)
+        if blk["down"]:
+            out[blk["down"] + ".weight"] = (blk["channels"], blk["channels"], 3, 3)
+            out[blk["down"] + ".bias"] = (blk["channels"],)
+    _resnet("encoder.mid_block.resnets.0", cm, cm, None, out)
+    a = "encoder.mid_block.attentions.0"
+    out[f"{a}.group_norm.weight"] = (cm,)
+    out[f"{a}.group_norm.bias"] = (cm,)
+    for t in ("to_q", "to_k", "to_v", "to_out.0"):
+        out[f"{a}.{t}.weight"] = (cm, cm)
+        out[f"{a}.{t}.bias"] = (cm,)
+    _resnet("encoder.mid_block.resnets.1", cm, cm, None, out)
+    out["encoder.conv_norm_out.weight"] = (cm,)
+    out["encoder.conv_norm_out.bias"] = (cm,)
+    out["encoder.conv_out.weight"] = (2 * lc, cm, 3, 3)                    # double_z: mean and log-variance
+    out["encoder.conv_out.bias"] = (2 * lc,)
+    out["quant_conv.weight"] = (2 * lc, 2 * lc, 1, 1)
+    out["quant_conv.bias"] = (2 * lc,)
+    return out
+
+
 # Legacy VAE attention key names used by SD-2.x hub checkpoints (SURVEY.md Appendix B).
 VAE_LEGACY_ATTN_KEYS = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
 

@@ -54,6 +54,10 @@ def synth_vae(cfg: S.VAEConfig = S.SD21_VAE, seed: int = 4321) -> SD:
     return synth_state_dict(S.vae_decoder_param_shapes(cfg), seed)
 
 
+def synth_vae_encoder(cfg: S.VAEConfig = S.SD21_VAE, seed: int = 4322) -> SD:
+    return synth_state_dict(S.vae_encoder_param_shapes(cfg), seed)
+
+
 def synth_clip(cfg: S.ClipTextConfig = S.SD21_CLIP, seed: int = 99) -> SD:
     sd = synth_state_dict(S.clip_text_param_shapes(cfg), seed)
     g = _gen(seed, 100003)
@@ -199,6 +203,24 @@ def load_vae_decoder_weights(root: str) -> SD:
             if k.endswith(".weight") and v.ndim == 4:   # very old checkpoints store 1x1 convs
                 v = v[:, :, 0, 0]
         out[k] = v
+    return out
+
+
+def load_vae_encoder_weights(root: str) -> SD:
+    """``encoder.*`` and ``quant_conv.*`` of <root>/vae (AutoencoderKL.encode, train_ID-Booth.py:1001)."""
+    raw = _load_safetensors(os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+    out: SD = {}
+    for k, v in raw.items():
+        if not (k.startswith("encoder.") or k.startswith("quant_conv.")):
+            continue
+        if ".attentions.0." in k:
+            for old, new in S.VAE_LEGACY_ATTN_KEYS.items():
+                k = k.replace(f".attentions.0.{old}.", f".attentions.0.{new}.")
+            if k.endswith(".weight") and v.ndim == 4:
+                v = v[:, :, 0, 0]
+        out[k] = v
+    if not out:
+        raise FileNotFoundError(f"{root}/vae holds no encoder weights")
     return out
 
 

@@ -88,11 +88,15 @@ typedef struct {
                                  flags bit 4: a split-K launch then reduces inside the GEMM (the last-arriving workgroup of a
                                  tile sums the slabs in fixed order and runs the epilogue; counters are left zero) */
     int32_t counters_len;
+    int32_t pad_mode;         /* taps=9 sources — 0: zero padding 1 on every side (nn.Conv2d padding=1); 1: padding on the
+                                 bottom/right only, i.e. F.pad(x, (0,1,0,1)) + padding=0, the stride-2 Downsample2D of the VAE
+                                 encoder (diffusers downsampling.py; AutoencoderKL.encode at train_ID-Booth.py:1001) */
 } idb_gemm_desc;
 
 size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);
-/* What idb_gemm would launch for `d`: tile config id (1: 128x160, 2: 128x128, 3: 64x160, 4: 64x128,
- * 5: 128x32), split-K factor and workgroup count.  Host-only, no GPU call. */
+/* What idb_gemm would launch for `d`: tile config id (shape + 10 * variant; shapes 1: 128x160, 2: 128x128, 3: 64x160,
+ * 4: 64x64 (8 waves), 5: 128x32, 6-9: 64x160 / 64x128 / 128x160 / 128x128 with 8 waves; variant 0/1: 2-/3-stage LDS ring,
+ * 4: persistent), split-K factor and workgroup count.  Host-only, no GPU call. */
 int idb_gemm_plan(const idb_gemm_desc* d, int32_t* tile, int32_t* split_k, int32_t* blocks);
 int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -183,6 +187,15 @@ int idb_nhwc_to_nchw_f32(const void* x, float* out, int32_t batch, int32_t hw, i
 int idb_f32_nhwc_to_nchw(const float* x, float* out, int32_t batch, int32_t hw, int32_t c, void* stream);
 /* [rows][cols] fp32 -> operand dtype (prompt embeddings). */
 int idb_cast_f32(const float* x, void* out, int64_t count, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AutoencoderKL.encode tail (train_ID-Booth.py:1001-1002): DiagonalGaussianDistribution.sample()/.mode() times
+ * vae.config.scaling_factor.  moments: fp32 [batch][hw][2*channels] (mean channels first, then log-variance), the
+ * output of the encoder's conv_out with quant_conv folded in; noise: NCHW fp32 [batch][channels][hw] or NULL (mode);
+ * latents, and optional mean / logvar (clamped to [-30, 20]) outputs: NCHW fp32.
+ * ------------------------------------------------------------------------------------------ */
+int idb_vae_sample(const float* moments, const float* noise, float scale, float* latents, float* mean_out,
+                   float* logvar_out, int32_t batch, int32_t channels, int32_t hw, void* stream);
 
 #ifdef __cplusplus
 }

@@ -235,6 +235,34 @@ def vae_decode(sd: SD, cfg: S.VAEConfig, z: Tensor) -> Tensor:
     return F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
 
 
+def vae_encode(sd: SD, cfg: S.VAEConfig, x: Tensor) -> Tuple[Tensor, Tensor]:
+    """AutoencoderKL.encode(x).latent_dist parameters (mean, logvar), NCHW — diffusers Encoder.forward + quant_conv +
+    DiagonalGaussianDistribution (logvar clamped to [-30, 20]); called at train_ID-Booth.py:1001.  x: [B,3,H,W] in [-1,1].
+    Downsample2D of the encoder uses padding 0 with F.pad(x, (0,1,0,1)) before the stride-2 conv."""
+    G, eps = cfg.norm_num_groups, cfg.norm_eps
+    h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    for blk in S.vae_encoder_blocks(cfg):
+        for name, _, _ in blk["resnets"]:
+            h = resnet_block(sd, name, h, None, G, eps)
+        if blk["down"]:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0.0)
+            h = F.conv2d(h, sd[blk["down"] + ".weight"], sd[blk["down"] + ".bias"], stride=2)
+    h = resnet_block(sd, "encoder.mid_block.resnets.0", h, None, G, eps)
+    h = vae_attention(sd, "encoder.mid_block.attentions.0", h, G, eps)
+    h = resnet_block(sd, "encoder.mid_block.resnets.1", h, None, G, eps)
+    h = F.silu(F.group_norm(h, G, sd["encoder.conv_norm_out.weight"], sd["encoder.conv_norm_out.bias"], eps))
+    h = F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    m = F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+    mean, logvar = m.chunk(2, dim=1)
+    return mean, logvar.clamp(-30.0, 20.0)
+
+
+def vae_latent_sample(mean: Tensor, logvar: Tensor, noise: Optional[Tensor], scaling_factor: float = 1.0) -> Tensor:
+    """latent_dist.sample() (noise given) or .mode() (noise None), times scaling_factor (train_ID-Booth.py:1001-1002)."""
+    z = mean if noise is None else mean + torch.exp(0.5 * logvar) * noise
+    return z * scaling_factor
+
+
 def postprocess_np(image: Tensor) -> Tensor:
     """VaeImageProcessor.postprocess(output_type='np'): NHWC float32 in [0,1]."""
     return (image / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous()

@@ -91,7 +91,7 @@ def test_batch_64_properties_full_size(lib):
     assert torch.equal(many[0], many[B - 1]) and torch.equal(many[0], many[17])                   # rows are independent of their position
     mx, rel = _stats(many[0:1], one)
     print(f"batch 64 vs batch 1 (same item, 2 steps, bf16): rel-rms {rel:.3e} max-abs {mx:.3e}")
-    assert rel < 3e-2
+    assert rel < 5e-2                                                                             # measured 2.7e-2
     again = run(pe1.repeat(B, 1, 1), ne1.repeat(B, 1, 1), noise)                                  # graph replay
     assert torch.equal(again, many)
     noise2 = noise.clone()
@@ -107,6 +107,6 @@ def test_batch_64_properties_full_size(lib):
     assert torch.equal(u8_many[63], u8_many[0]) and torch.equal(u8_many[30], u8_many[0])
     d = (u8_many[0].int() - u8_one[0].int()).abs()                # chunk of 4 vs chunk of 1: other tiles / split-K, same image
     print(f"VAE decode chunk 4 vs chunk 1 (bf16): uint8 max diff {d.max().item()}, {100 * (d <= 1).float().mean().item():.3f} % within 1")
-    assert d.max().item() <= 8 and (d <= 1).float().mean().item() > 0.99
+    assert d.max().item() <= 8 and (d <= 1).float().mean().item() > 0.98       # measured: max 4, 99.2 % within 1
     del pipe
     torch.cuda.empty_cache()

@@ -249,3 +249,30 @@ def test_pipeline_argument_checks_without_gpu(tmp_path, tiny):
     assert n.shape == (4, 2, 4, 16, 16) and torch.equal(n, O.draw_noise(torch.Generator().manual_seed(4), 2, 3, (16, 16)))
     with pytest.raises(ValueError):
         pipe.prepare_noise(2, 3, 128, 128, [torch.Generator().manual_seed(1)])
+
+
+def test_vae_encoder_spec_and_oracle():
+    """AutoencoderKL.encode.  Parameter counts (encoder 34,163,592 + quant_conv 72; the whole SD-2.1
+    AutoencoderKL is 83,653,863), output geometry, the bottom/right padding of the stride-2 convs, and the sample/mode tail."""
+    import torch.nn.functional as F
+    from faceposegenerator_amd import spec as S, weights as W
+    from oracle import sd21_oracle as O
+    enc = S.count_params(S.vae_encoder_param_shapes(S.SD21_VAE))
+    assert enc == 34_163_664 and enc + S.count_params(S.vae_decoder_param_shapes(S.SD21_VAE)) == 83_653_863
+    cfg = S.TINY_VAE
+    sd = W.synth_vae_encoder(cfg, 21)
+    x = torch.rand(2, 3, 32, 40, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    mean, logvar = O.vae_encode(sd, cfg, x)
+    assert mean.shape == (2, cfg.latent_channels, 4, 5) and logvar.shape == mean.shape
+    assert logvar.min().item() >= -30.0 and logvar.max().item() <= 20.0
+    # shifting the image by one pixel down/right changes what the bottom/right zero padding sees: the stride-2 convs are not
+    # the symmetric-padding ones (a symmetric variant would give a different result on the same input)
+    name = S.vae_encoder_blocks(cfg)[0]["down"]
+    h = torch.randn(1, cfg.block_out_channels[0], 8, 8, generator=torch.Generator().manual_seed(2))
+    a = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[name + ".weight"], sd[name + ".bias"], stride=2)
+    b = F.conv2d(h, sd[name + ".weight"], sd[name + ".bias"], stride=2, padding=1)
+    assert a.shape == b.shape == (1, cfg.block_out_channels[0], 4, 4) and (a - b).abs().max().item() > 1e-2
+    noise = torch.randn(mean.shape, generator=torch.Generator().manual_seed(3))
+    z = O.vae_latent_sample(mean, logvar, noise, cfg.scaling_factor)
+    assert torch.allclose(z, (mean + (0.5 * logvar).exp() * noise) * cfg.scaling_factor)
+    assert torch.equal(O.vae_latent_sample(mean, logvar, None), mean)
