@@ -617,7 +617,7 @@ class HipEngine:
     # ------------------------------------------------------------------------------------
     # sampling loop (StableDiffusionPipeline.__call__ steps 3-5)
     # ------------------------------------------------------------------------------------
-    def _sample_body(self, ctx_f32, noise, coefs, tp, lat, eps, steps, rep, n_ctx, vpred, trace=None) -> None:
+    def _sample_body(self, ctx_f32, noise, coefs, tp, lat, eps, steps, rep, n_ctx, vpred, trace=None, hist=None) -> None:
         """One whole sampling loop on the current stream; every buffer is passed in, so the same
         code runs eagerly or under HIP-graph capture."""
         B = noise.shape[1]
@@ -625,6 +625,8 @@ class HipEngine:
         self.arena.reset()
         self._pinned.clear()
         lat.copy_(noise[0])                                  # init_noise_sigma = 1
+        if hist is not None:
+            hist.zero_()                                     # multistep solver: x0 history (coefficient 0 on the first step)
         ctx = self.arena.alloc(tuple(ctx_f32.shape), self.tdt)
         L.check(self.lib.idb_cast_f32(ctx_f32.data_ptr(), ctx.data_ptr(), ctx_f32.numel(), self.dt, _stream()), "idb_cast_f32")
         kv = {}
@@ -635,18 +637,24 @@ class HipEngine:
         self.arena.free(ctx)
         for i in range(steps):
             self.unet_nhwc(lat, rep, (tp, i * self.tproj_total, 0), kv, n_ctx, eps_out=eps)
-            L.check(self.lib.idb_cfg_ddpm_step(eps.data_ptr(), lat.data_ptr(), noise[i + 1].data_ptr(), coefs[i].data_ptr(),
-                                               None, B, lat.shape[1], h * w_, int(rep == 2), int(vpred), _stream()),
+            if hist is None:                                 # DDPM: third operand = this step's variance noise
+                third, x0_out = noise[i + 1].data_ptr(), None
+            else:                                            # DPM-Solver++ 2M: third operand = previous x0 prediction; keep this one
+                third, x0_out = hist[(i + 1) & 1].data_ptr(), hist[i & 1].data_ptr()
+            L.check(self.lib.idb_cfg_ddpm_step(eps.data_ptr(), lat.data_ptr(), third, coefs[i].data_ptr(),
+                                               x0_out, B, lat.shape[1], h * w_, int(rep == 2), int(vpred), _stream()),
                     "idb_cfg_ddpm_step")
             if trace is not None:
                 trace.append((eps.clone(), lat.clone()))
 
     def sample(self, prompt_embeds: torch.Tensor, negative_prompt_embeds: Optional[torch.Tensor], noise: torch.Tensor,
                timesteps: Sequence[int], coefs: torch.Tensor, vpred: bool = False, use_graph: bool = False,
-               trace: Optional[list] = None) -> torch.Tensor:
+               trace: Optional[list] = None, multistep: bool = False) -> torch.Tensor:
         """noise: [steps+1, B, 4, h, w] fp32 on device (noise[0] = initial latents); coefs: [steps, 6] fp32 on
         device (sqrt_a, sqrt_b, c_x0, c_x, sigma, guidance_scale).  CFG is on iff negative_prompt_embeds is
-        given.  Returns final latents [B,4,h,w] fp32.  ``trace`` collects (eps [2B*hw,4], latents) per step."""
+        given.  Returns final latents [B,4,h,w] fp32.  ``trace`` collects (eps [2B*hw,4], latents) per step.
+        multistep (DPM-Solver++ 2M, train_ID-Booth.py:155): noise is [1, B, 4, h, w] (initial latents only) and the fifth
+        coefficient multiplies the previous step's x0 prediction instead of fresh noise."""
         steps = len(timesteps)
         B, lc, h, w_ = noise.shape[1:]
         cfg_on = negative_prompt_embeds is not None
@@ -661,17 +669,19 @@ class HipEngine:
         if not use_graph or trace is not None:
             lat = torch.empty((B, lc, h, w_), dtype=torch.float32, device=self.device)
             eps = torch.empty((rep * B * h * w_, self.ucfg.out_channels), dtype=torch.float32, device=self.device)
-            self._sample_body(ctx_f32, noise, coefs, tp, lat, eps, steps, rep, n_ctx, vpred, trace)
+            hist = torch.empty((2, B, lc, h, w_), dtype=torch.float32, device=self.device) if multistep else None
+            self._sample_body(ctx_f32, noise, coefs, tp, lat, eps, steps, rep, n_ctx, vpred, trace, hist)
             return lat
         if not hasattr(self, "_graphs"):
             self._graphs = {}
-        key = ("sample", B, lc, h, w_, steps, n_ctx, cfg_on, vpred, self.dtype_name)
+        key = ("sample", B, lc, h, w_, steps, n_ctx, cfg_on, vpred, self.dtype_name, multistep)
         ent = self._graphs.get(key)
         if ent is None:
             ent = {"ctx": ctx_f32.clone(), "noise": noise.clone(), "coefs": coefs.clone(), "tp": tp.clone(),
                    "lat": torch.empty((B, lc, h, w_), dtype=torch.float32, device=self.device),
                    "eps": torch.empty((rep * B * h * w_, self.ucfg.out_channels), dtype=torch.float32, device=self.device)}
-            args = (ent["ctx"], ent["noise"], ent["coefs"], ent["tp"], ent["lat"], ent["eps"], steps, rep, n_ctx, vpred)
+            hist = torch.empty((2, B, lc, h, w_), dtype=torch.float32, device=self.device) if multistep else None
+            args = (ent["ctx"], ent["noise"], ent["coefs"], ent["tp"], ent["lat"], ent["eps"], steps, rep, n_ctx, vpred, None, hist)
             self._sample_body(*args)                     # eager warm-up: allocates every arena block, sets func attributes
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()

@@ -26,7 +26,7 @@ import torch
 
 from . import spec as S
 from . import weights as W
-from .scheduler import DDPMScheduler
+from .scheduler import DDPMScheduler, DPMSolverMultistepScheduler
 
 
 class StableDiffusionPipelineOutput:
@@ -313,15 +313,21 @@ class StableDiffusionPipeline:
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps)
         timesteps = sch.timesteps.tolist()
+        multistep = isinstance(sch, DPMSolverMultistepScheduler)         # deterministic solver: initial latents only
         if noise is None:
-            noise = self.prepare_noise(B, num_inference_steps, height, width, generator)
+            noise = self.prepare_noise(B, 0 if multistep else num_inference_steps, height, width, generator)
         if latents is not None:
             noise = noise.clone()
             noise[0] = latents.float().cpu() * sch.init_noise_sigma
-        coefs = torch.tensor([list(sch.step_coefficients(t)) + [float(guidance_scale)] for t in timesteps], dtype=torch.float32)
+        if multistep:
+            noise = noise[:1]
+            coefs = torch.tensor([list(sch.step_coefficients(i)) + [float(guidance_scale)] for i in range(len(timesteps))],
+                                 dtype=torch.float32)
+        else:
+            coefs = torch.tensor([list(sch.step_coefficients(t)) + [float(guidance_scale)] for t in timesteps], dtype=torch.float32)
         lat = eng.sample(prompt_embeds, negative_prompt_embeds if do_cfg else None, noise.to(self.device), timesteps,
                          coefs.to(self.device), vpred=(sch.config.prediction_type == "v_prediction"),
-                         use_graph=self.use_graph)
+                         use_graph=self.use_graph, multistep=multistep)
         if output_type == "latent":
             images = lat
         else:

@@ -360,6 +360,62 @@ def sample(unet_sd: SD, ucfg: S.UNetConfig, prompt_embeds: Tensor, negative_prom
     return latents
 
 
+# ----------------------------------------------------------------------------------------
+# DPM-Solver++ (2M) — the validation sampler of train_ID-Booth.py:155 (diffusers scheduling_dpmsolver_multistep.py with
+# its defaults on SD-2.1's scheduler config: dpmsolver++, order 2, midpoint, lower_order_final, final sigma zero,
+# "leading" spacing).  Restated from the published algorithm (Lu et al. 2022, "DPM-Solver++", Alg. 2) in upstream's
+# sigma parameterisation; PARITY UNPINNED like the rest of this file, except for the analytic checks in
+# tests/test_oracle_cpu.py (order 1 == DDIM, last step returns the x0 prediction).
+# ----------------------------------------------------------------------------------------
+def dpmpp_timesteps_sigmas(n: int, cfg: S.SchedulerConfig = S.SD21_SCHED) -> Tuple[List[int], Tensor]:
+    ac = ddpm_tables(cfg).double()
+    ratio = cfg.num_train_timesteps // (n + 1)
+    ts = [int(round(i * ratio)) + cfg.steps_offset for i in range(n + 1)][::-1][:-1]
+    sig = ((1 - ac) / ac) ** 0.5
+    sigmas = torch.cat([sig[torch.tensor(ts)], torch.zeros(1, dtype=torch.float64)]).float()
+    return ts, sigmas
+
+
+def dpmpp_2m_sample(unet_sd: SD, ucfg: S.UNetConfig, prompt_embeds: Tensor, negative_prompt_embeds: Tensor, latents: Tensor,
+                    num_inference_steps: int, guidance_scale: float, lora: Optional[SD] = None,
+                    sched: S.SchedulerConfig = S.SD21_SCHED, solver_order: int = 2, model=None) -> Tensor:
+    """``model(x, t) -> guided model output`` may replace the UNet (analytic tests)."""
+    ts, sigmas = dpmpp_timesteps_sigmas(num_inference_steps, sched)
+    ctx = torch.cat([negative_prompt_embeds, prompt_embeds]) if model is None else None
+
+    def conv(sigma):
+        alpha_t = 1.0 / (sigma ** 2 + 1.0) ** 0.5
+        return alpha_t, sigma * alpha_t
+
+    x = latents * 1.0
+    x0_hist: List[Tensor] = []
+    for i, t in enumerate(ts):
+        if model is None:
+            eps = unet_forward(unet_sd, ucfg, torch.cat([x] * 2), t, ctx, lora)
+            e_u, e_c = eps.chunk(2)
+            out = e_u + guidance_scale * (e_c - e_u)
+        else:
+            out = model(x, t)
+        alpha_s0, sigma_s0 = conv(sigmas[i])
+        x0 = alpha_s0 * x - sigma_s0 * out if sched.prediction_type == "v_prediction" else (x - sigma_s0 * out) / alpha_s0
+        x0_hist.append(x0)
+        alpha_t, sigma_t = conv(sigmas[i + 1])
+        lam_t = torch.log(alpha_t) - torch.log(sigma_t)
+        lam_s0 = torch.log(alpha_s0) - torch.log(sigma_s0)
+        h = lam_t - lam_s0
+        last = i == len(ts) - 1
+        if solver_order == 1 or i == 0 or last:
+            x = (sigma_t / sigma_s0) * x - (alpha_t * (torch.exp(-h) - 1.0)) * x0
+        else:
+            alpha_s1, sigma_s1 = conv(sigmas[i - 1])
+            lam_s1 = torch.log(alpha_s1) - torch.log(sigma_s1)
+            h_0 = lam_s0 - lam_s1
+            r0 = h_0 / h
+            d0, d1 = x0_hist[-1], (1.0 / r0) * (x0_hist[-1] - x0_hist[-2])
+            x = (sigma_t / sigma_s0) * x - (alpha_t * (torch.exp(-h) - 1.0)) * d0 - 0.5 * (alpha_t * (torch.exp(-h) - 1.0)) * d1
+    return x
+
+
 def decode_to_images(vae_sd: SD, vcfg: S.VAEConfig, latents: Tensor) -> Tensor:
     """latents -> NHWC float32 [0,1] (what ``output_type='np'`` returns)."""
     return postprocess_np(vae_decode(vae_sd, vcfg, latents / vcfg.scaling_factor))

@@ -110,3 +110,35 @@ def test_batch_64_properties_full_size(lib):
     assert d.max().item() <= 8 and (d <= 1).float().mean().item() > 0.98       # measured: max 4, 99.2 % within 1
     del pipe
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 8e-2), ("f16", 1.2e-2)])
+def test_dpm_solver_pp_validation_sampler_matches_oracle(lib, dtype, tol):
+    """The reference's validation sampler (train_ID-Booth.py:155): ``pipeline.scheduler = DPMSolverMultistepScheduler.from_config(
+    pipeline.scheduler.config, **scheduler_args)`` then ``pipeline(prompt..., num_inference_steps=25)``.  Here: 8 steps, guidance
+    7.5 (upstream's default), reduced-width graph, eager and HIP-graph, against oracle.dpmpp_2m_sample; the x0 history lives in
+    the engine and the update is idb_cfg_ddpm_step with the previous x0 prediction as its third operand."""
+    from faceposegenerator_amd import spec as S, weights as W
+    from faceposegenerator_amd.pipeline import StableDiffusionPipeline
+    from faceposegenerator_amd.scheduler import DPMSolverMultistepScheduler
+    from oracle import sd21_oracle as O
+    ucfg, usd, vsd = S.TINY_UNET, W.synth_unet(S.TINY_UNET, 7), W.synth_vae(S.TINY_VAE, 8)
+    g = torch.Generator().manual_seed(13)
+    pe, ne = torch.randn(2, 77, ucfg.cross_attention_dim, generator=g), torch.randn(2, 77, ucfg.cross_attention_dim, generator=g)
+    init = torch.randn(2, 4, 16, 16, generator=g)
+    steps, gs = 8, 7.5
+    ref = O.dpmpp_2m_sample(usd, ucfg, pe, ne, init, steps, gs)
+    ref1 = O.dpmpp_2m_sample(usd, ucfg, pe, ne, init, steps, gs, solver_order=1)
+    assert (ref - ref1).abs().max().item() > 1e-2                     # the second-order terms matter on these inputs
+    pipe = StableDiffusionPipeline(ucfg, S.TINY_VAE, usd, vsd, torch_dtype=dtype).to(DEV)
+    pipe.scheduler = DPMSolverMultistepScheduler.from_config(pipe.scheduler.config, variance_type="fixed_small")
+    for use_graph in (False, True, True):
+        pipe.use_graph = use_graph
+        out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=steps, guidance_scale=gs, height=128, width=128,
+                   output_type="latent", latents=init)
+        mx, rel = _stats(out.images, ref)
+        print(f"[{dtype}] DPM-Solver++ 2M sampler graph={use_graph}: latents max-abs {mx:.3e} rel-rms {rel:.3e}")
+        assert rel < tol
+    img = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=steps, guidance_scale=gs, height=128, width=128,
+               output_type="np", generator=torch.Generator().manual_seed(1)).images
+    assert img.shape == (2, 128, 128, 3) and 0.0 <= img.min() and img.max() <= 1.0
