@@ -33,6 +33,7 @@ struct GemmParams {
     int M, N, HW, OW, stride, pad;
     unsigned w_row_bytes, w_bytes;
     int ktiles, kt_per_split, splitk;
+    int xcd_mode;   // 0: tiles dealt to XCDs in runs, K-split on grid z; 1/2: one K-slice per XCD (group), see idb_gemm_kernel
     const char* w;
     const float* bias;
     const float* sbias;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
 // outputs / split-K slabs / odd widths.
 template <typename T, int MF, int NF, int WM = 2>
 __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
-                                                  int wm, int wn, int fr, int fg) {
+                                                  int wm, int wn, int fr, int fg, int kz) {
     if (p.dbg_skip_store == 1) {            // profiling experiment: keep the accumulators live, write nothing
         float keep = 0.f;
 #pragma unroll
@@ -172,7 +173,7 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
         for (int i = 0; i < MF; ++i) {
             const int m = m0 + (wm * MF + i) * 16 + fr;
             if (m >= p.M) continue;
-            float* dst = p.partial + ((long long)blockIdx.z * p.M + m) * p.N;
+            float* dst = p.partial + ((long long)kz * p.M + m) * p.N;
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 const int n = n0 + (wn * NF + j) * 16 + fg * 4;
@@ -342,16 +343,37 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
 
-    // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
-    // contiguous run of tiles so neighbours re-use the same activation rows from that L2.
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    // XCD-aware bijective remaps (workgroups are dealt round-robin over the 8 XCDs in linear-id order, so ids b and b+8 share
+    // an XCD and its L2; the 8 L2s are not coherent and do not share lines).
+    //  mode 0: each XCD gets a contiguous run of tiles, so neighbours re-use the same activation rows from that L2; the K
+    //          split, if any, is the grid's z.
+    //  mode 1 (split-K, S % 8 == 0) / mode 2 (S == 4): each XCD owns ONE K-slice (mode 2: half the tiles of one) of EVERY
+    //          tile, so every weight and activation byte crosses the fabric once instead of once per XCD — on the batch-1
+    //          weight-streaming layers (M = 512: 4 row tiles on 4 XCD pairs) mode 0 fetched the weights 4-8 times
+    //          (rocprofv3 FETCH_SIZE: 99-113 MB per launch against 28-40 MB of operands).
+    int wg, kz;
+    if (p.xcd_mode == 0) {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        kz = blockIdx.z;
+    } else {
+        const int X = gridDim.x;
+        const int lin = blockIdx.x + X * blockIdx.z;
+        const int xcd = lin & 7, j = lin >> 3;
+        if (p.xcd_mode == 1) {
+            kz = xcd + 8 * (j / X);
+            wg = j % X;
+        } else {
+            kz = xcd >> 1;
+            wg = (xcd & 1) * (X >> 1) + j;
+        }
+    }
     const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int kt0 = blockIdx.z * p.kt_per_split;
-    const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+    const int kt0 = (int)(((long long)kz * p.ktiles) / p.splitk);          // balanced partition: slice sizes differ by at most one
+    const int kt1 = (int)(((long long)(kz + 1) * p.ktiles) / p.splitk);
     const int nk = kt1 - kt0;
 
     // ---- per-thread staging coordinates: thread loads chunk position (tid&7) of rows (tid>>3)+32i;
@@ -494,7 +516,7 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
 
-    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, kz);
 #endif
 }
 
@@ -524,8 +546,9 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_rs(const GemmParams p)
     const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int kt0 = blockIdx.z * p.kt_per_split;
-    const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+    const int kz = blockIdx.z;
+    const int kt0 = (int)(((long long)kz * p.ktiles) / p.splitk);
+    const int kt1 = (int)(((long long)(kz + 1) * p.ktiles) / p.splitk);
     const int nk = kt1 - kt0;
 
     // thread stages chunk (tid&7) of rows (tid>>3)+32i: global chunk c lands at LDS chunk position c ^ (row&7)
@@ -655,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_rs(const GemmParams p)
         if (it + 1 < nk) lstore(cur ^ 1);               // the other buffer was last read one barrier ago
         __syncthreads();
     }
-    idb_gemm_epilogue<T, MF, NF>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+    idb_gemm_epilogue<T, MF, NF>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, kz);
 #endif
 }
 
@@ -1073,8 +1096,21 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     IDB_REQUIRE(!(d->geglu && sk > 1), "idb_gemm: GEGLU does not support split-K");
     if (d->act) sk = 1;
     if (sk > pl->ktiles) sk = pl->ktiles;
+    if (sk < 1) sk = 1;
+    if (d->split_k <= 0 && !(d->flags & 16) && pl->tile / 10 <= 1 && kTiles[tile].wm == 4) {
+        // one K-slice per XCD (kernel remap modes 1/2) needs S % 8 == 0 or S == 4: round the heuristic's choice
+        static const int env_xcd = [] { const char* e = getenv("IDB_GEMM_XCD_SLICES"); return e ? atoi(e) : 1; }();
+        if (env_xcd) {
+            if (sk > 8) {
+                const int up = ((sk + 7) / 8) * 8;
+                sk = (up <= 32 && up * 6 <= pl->ktiles) ? up : (sk / 8) * 8;
+            } else if (sk >= 5) {
+                sk = (8 * 6 <= pl->ktiles) ? 8 : 4;
+            }
+        }
+    }
+    pl->splitk = sk;
     pl->kt_per_split = (pl->ktiles + sk - 1) / sk;
-    pl->splitk = (pl->ktiles + pl->kt_per_split - 1) / pl->kt_per_split;
     return IDB_OK;
 }
 
@@ -1225,6 +1261,16 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.w_bytes = (unsigned)((long long)d->n * pl.K * 2);
     p.ktiles = pl.ktiles;
     p.kt_per_split = pl.kt_per_split;
+    {
+        // K-slice-per-XCD remap: the 8-wave ring kernels only (the register-staged and persistent variants keep mode 0)
+        static const int env_xcd = [] { const char* e = getenv("IDB_GEMM_XCD_SLICES"); return e ? atoi(e) : 1; }();
+        const long long X = (long long)pl.tiles_m * pl.tiles_n;
+        p.xcd_mode = 0;
+        if (env_xcd && pl.tile / 10 <= 1 && pl.tile % 10 != 5 && pl.tile % 10 != 0) {
+            if (pl.splitk >= 8 && pl.splitk % 8 == 0) p.xcd_mode = 1;
+            else if (pl.splitk == 4 && X % 2 == 0) p.xcd_mode = 2;
+        }
+    }
     p.splitk = pl.splitk;
     p.w = (const char*)d->w;
     p.bias = d->bias;
