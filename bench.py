@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-_TILE_SHAPES = {1: "128x160", 2: "128x128", 3: "64x160", 4: "64x128", 5: "128x32",
+_TILE_SHAPES = {1: "128x160", 2: "128x128", 3: "64x160", 4: "64x64,8w", 5: "128x32",
                 6: "64x160,8w", 7: "64x128,8w", 8: "128x160,8w", 9: "128x128,8w"}
 _TILE_VARIANTS = {0: "idb_gemm_kernel<{},ring2>", 1: "idb_gemm_kernel<{},ring3>", 2: "idb_gemm_kernel<{},ring4>",
                   3: "idb_gemm_kernel_rs<{}>", 4: "idb_gemm_kernel_pl<{}>"}
