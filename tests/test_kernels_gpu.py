@@ -282,7 +282,9 @@ def test_softmax_rows(eng):
 # ---------------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("b,heads,n", [(2, 5, 1024), (1, 2, 4096), (3, 4, 64), (2, 20, 256), (1, 3, 144)])
+# (2,10,1024), (3,7,1000): grids of 128-256 workgroups -> the 8-wave key-split form (wave pairs merge through LDS);
+# (2,5,4096), (2,11,1600): 257-511 workgroups of 128 rows -> the 12-wave 192-row form
+@pytest.mark.parametrize("b,heads,n", [(2, 5, 1024), (1, 2, 4096), (3, 4, 64), (2, 20, 256), (1, 3, 144), (2, 5, 4096), (2, 10, 1024), (3, 7, 1000), (2, 11, 1600)])
 def test_self_attention(eng, b, heads, n):
     c = heads * 64
     qkv = _rand((b * n, 3 * c), 60).to(eng.tdt)
@@ -296,12 +298,16 @@ def test_self_attention(eng, b, heads, n):
 
 def test_attention_peaked_softmax(eng):
     """One dominant key per query (forces the online-softmax running max to jump between tiles)."""
-    b, heads, n = 1, 2, 512
+    _peaked(eng, 1, 2, 512)
+    _peaked(eng, 2, 10, 1024)            # key-split form: the dominant key of a query sits in either wave's half of a tile
+
+
+def _peaked(eng, b, heads, n):
     c = heads * 64
     g = torch.Generator().manual_seed(61)
     q = torch.randn(b * n, c, generator=g)
     k = torch.randn(b * n, c, generator=g)
-    idx = torch.randperm(n, generator=g)
+    idx = torch.cat([torch.randperm(n, generator=g) + j * n for j in range(b)])
     k[idx] += 3.0 * q                      # key idx[i] aligned with query i -> large logit late/early in the sweep
     v = torch.randn(b * n, c, generator=g)
     qkv = torch.cat([q, k, v], -1).to(DEV).to(eng.tdt)
@@ -313,7 +319,7 @@ def test_attention_peaked_softmax(eng):
     _check(out, ref, _tol(eng), "peaked attention")
 
 
-@pytest.mark.parametrize("b,heads,n,n_ctx", [(2, 5, 1024, 77), (2, 20, 64, 77), (1, 10, 256, 64), (1, 1, 128, 130)])
+@pytest.mark.parametrize("b,heads,n,n_ctx", [(2, 5, 1024, 77), (2, 20, 64, 77), (1, 10, 256, 64), (1, 1, 128, 130), (2, 10, 1024, 600), (2, 10, 1024, 545)])
 def test_cross_attention(eng, b, heads, n, n_ctx):
     c = heads * 64
     qm = _rand((b * n, c), 70).to(eng.tdt)
