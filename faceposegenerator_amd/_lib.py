@@ -41,7 +41,8 @@ class GemmDesc(C.Structure):
                 ("sample_bias_ld", C.c_int32), ("residual", C.c_void_p), ("geglu", C.c_int32),
                 ("out", C.c_void_p), ("out_dtype", C.c_int32), ("out_ld", C.c_int32),
                 ("split_k", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float), ("flags", C.c_int32), ("act", C.c_int32),
-                ("counters", C.c_void_p), ("counters_len", C.c_int32), ("pad_mode", C.c_int32)]
+                ("counters", C.c_void_p), ("counters_len", C.c_int32), ("gn_partials", C.c_void_p), ("gn_groups", C.c_int32),
+                ("pad_mode", C.c_int32)]
 
 
 class IdbError(RuntimeError):
@@ -72,7 +73,7 @@ def load() -> C.CDLL:
         "idb_pack_matrix": (C.c_int, [vp, vp, i64, i64, i32, i32, vp]),
         "idb_lora_merge": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, i32, vp]),
         "idb_groupnorm_workspace_bytes": (sz, [i32, i32, i32]),
-        "idb_groupnorm": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp, sz, vp, i32, vp]),
+        "idb_groupnorm": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp, sz, vp, i32, vp, i32, vp]),
         "idb_layernorm": (C.c_int, [vp, vp, i64, i32, f32, vp, vp, i32, vp]),
         "idb_attention": (C.c_int, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp]),
         "idb_embed_tokens": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -105,3 +105,7 @@ const void* idb_zero_page(void);   // >= 256 zero bytes in device memory (paddin
 
 static inline bool idb_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline bool idb_is_operand_dtype(int dt) { return dt == IDB_BF16 || dt == IDB_F16; }
+
+// idb_norm.hip: first GroupNorm pass over a dense [batch][hw][c] tensor with one partial per 64-row block (the layout of
+// idb_gemm_desc.gn_partials); used by idb_gemm when its own launches cannot produce the statistics.
+int idb_launch_gn_stats64(const void* x, int c, int batch, int hw, int groups, float* partial, int dtype, hipStream_t st);

@@ -463,8 +463,21 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int cols) {
 
 template <typename T>
 int run_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
-                  const float* gamma, const float* beta, int silu, void* out, void* ws, int* sync, int sync_len, hipStream_t st) {
+                  const float* gamma, const float* beta, int silu, void* out, void* ws, int* sync, int sync_len, const float* pin,
+                  int pin_chunks, hipStream_t st) {
     GnGeom g = gn_geometry(c0, c1, batch, hw, groups);
+    if (pin) {                                   // statistics came with the tensor (idb_gemm_desc.gn_partials): normalise only
+        g.nchunks = pin_chunks;
+        g.chunk_len = 64;
+        int want = (2048 + batch * g.nslices - 1) / (batch * g.nslices);
+        int ppb = (hw + want - 1) / want;
+        if (ppb < g.PR * 2) ppb = g.PR * 2;
+        const int nblk = (hw + ppb - 1) / ppb;
+        hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, g.nslices, batch), dim3(GN_THREADS), 0, st, (const T*)x0, (const T*)x1, g,
+                           pin, gamma, beta, eps, silu, (T*)out, ppb);
+        IDB_CHECK_LAUNCH("idb_groupnorm(apply)");
+        return IDB_OK;
+    }
     {
         // single launch when the caller passes hand-off counters and every workgroup of the grid is resident at once (see
         // gn_sync_kernel).  Measured in the sampling loop (batch 1, A/B on one box): 6.05 images/s against 6.28 for the
@@ -500,6 +513,23 @@ int run_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int
 
 }  // namespace
 
+int idb_launch_gn_stats64(const void* x, int c, int batch, int hw, int groups, float* partial, int dtype, hipStream_t st) {
+    IDB_REQUIRE(x && partial && hw % 64 == 0 && hw / 64 <= GN_MAXCHUNKS && c % 8 == 0 && c % groups == 0 && c / groups >= 2,
+                "idb_gemm: gn_partials unsupported for hw=%d c=%d groups=%d", hw, c, groups);
+    GnGeom g = gn_geometry(c, 0, batch, hw, groups);
+    IDB_REQUIRE(g.cols <= GN_THREADS && g.gps <= 64, "idb_gemm: gn_partials unsupported geometry");
+    g.nchunks = hw / 64;
+    g.chunk_len = 64;
+    if (dtype == IDB_BF16)
+        hipLaunchKernelGGL((gn_stats_kernel<__bf16>), dim3(g.nchunks, g.nslices, batch), dim3(GN_THREADS), 0, st, (const __bf16*)x,
+                           (const __bf16*)nullptr, g, partial);
+    else
+        hipLaunchKernelGGL((gn_stats_kernel<_Float16>), dim3(g.nchunks, g.nslices, batch), dim3(GN_THREADS), 0, st, (const _Float16*)x,
+                           (const _Float16*)nullptr, g, partial);
+    IDB_CHECK_LAUNCH("idb_gemm(gn stats)");
+    return IDB_OK;
+}
+
 extern "C" size_t idb_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups) {
     if (batch <= 0 || hw <= 0 || groups <= 0) return 0;
     return (size_t)batch * GN_MAXCHUNKS * groups * 2 * sizeof(float);
@@ -508,7 +538,7 @@ extern "C" size_t idb_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32
 extern "C" int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw,
                              int32_t groups, float eps, const float* gamma, const float* beta, int32_t silu, void* out,
                              int32_t dtype, void* workspace, size_t workspace_bytes, int32_t* sync, int32_t sync_len,
-                             void* stream) {
+                             const float* partials_in, int32_t partials_chunks, void* stream) {
     IDB_REQUIRE(idb_is_operand_dtype(dtype), "idb_groupnorm: dtype must be bf16/f16");
     IDB_REQUIRE(x0 && out && gamma && beta && idb_aligned16(x0) && idb_aligned16(out) && idb_aligned16(gamma) && idb_aligned16(beta),
                 "idb_groupnorm: null/unaligned pointer");
@@ -526,10 +556,15 @@ extern "C" int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t
     const size_t need = idb_groupnorm_workspace_bytes(batch, hw, groups);
     IDB_REQUIRE(workspace && workspace_bytes >= need, "idb_groupnorm: workspace too small (%zu < %zu)", workspace_bytes, need);
     IDB_REQUIRE(!sync || (sync_len > 0 && ((uintptr_t)sync & 3) == 0), "idb_groupnorm: bad sync counter array");
+    IDB_REQUIRE(!partials_in || (c1 == 0 && hw % 64 == 0 && partials_chunks == hw / 64 && partials_chunks <= GN_MAXCHUNKS &&
+                                 ((uintptr_t)partials_in & 7) == 0),
+                "idb_groupnorm: partials_in needs one dense input, hw %% 64 == 0, partials_chunks == hw / 64 <= %d", GN_MAXCHUNKS);
     hipStream_t st = (hipStream_t)stream;
     return dtype == IDB_BF16
-               ? run_groupnorm<__bf16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out, workspace, sync, sync_len, st)
-               : run_groupnorm<_Float16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out, workspace, sync, sync_len, st);
+               ? run_groupnorm<__bf16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out, workspace, sync, sync_len, partials_in,
+                                       partials_chunks, st)
+               : run_groupnorm<_Float16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out, workspace, sync, sync_len, partials_in,
+                                         partials_chunks, st);
 }
 
 extern "C" int idb_layernorm(const void* x, void* out, int64_t rows, int32_t c, float eps, const float* gamma,

@@ -113,6 +113,8 @@ class HipEngine:
         self._counters = torch.zeros(1 << 16, dtype=torch.int32, device=self.device)   # split-K tickets (self-resetting)
         # GroupNorm single-launch hand-off counters (self-resetting); opt-in: measured slower than two launches (idb_norm.hip)
         self._gn_sync = torch.zeros(1 << 14, dtype=torch.int32, device=self.device) if os.environ.get("IDB_GN_SYNC") == "1" else None
+        # first GroupNorm pass produced by the GEMM that writes the tensor (idb_gemm_desc.gn_partials); IDB_GN_FUSE=0 disables
+        self._gn_fuse = os.environ.get("IDB_GN_FUSE", "1") != "0"
         self.w: Dict[str, torch.Tensor] = {}
         self.master: Dict[str, torch.Tensor] = {}
         self.tproj_off: Dict[str, int] = {}
@@ -357,7 +359,8 @@ class HipEngine:
 
     def gemm(self, srcs, w: torch.Tensor, n: int, batch: int, oh: int, ow: int, bias=None, sbias=None,
              residual=None, geglu=False, stride=1, out_f32=False, out_scale=0.0, split_k=0, tile=0,
-             out: Optional[torch.Tensor] = None, flags: int = 0, act: int = 0, pad_mode: int = 0) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, flags: int = 0, act: int = 0, pad_mode: int = 0, gn_stats: int = 0,
+             gn_stats_always: bool = False) -> torch.Tensor:
         """srcs: list of (tensor, channels, taps, in_h, in_w, upsample); sbias: (tensor, elem_offset, ld)."""
         m = batch * oh * ow
         ncols = n // 2 if geglu else n
@@ -376,6 +379,15 @@ class HipEngine:
         d.out, d.out_dtype, d.out_ld = out.data_ptr(), (L.IDB_F32 if out_f32 else self.dt), out.shape[-1]
         d.split_k, d.tile, d.out_scale, d.flags, d.act = split_k, tile, out_scale, flags, act
         d.pad_mode = pad_mode
+        gn_part = None
+        if gn_stats and self._gn_fuse and (oh * ow) % 64 == 0 and oh * ow <= 4096 and not geglu and not out_f32 and n % gn_stats == 0:
+            # the GroupNorm that consumes `out` next gets its first pass from this GEMM's split-K reduce launch (idb_kernels.h);
+            # without a split there is no launch to ride on and the ordinary two-pass GroupNorm is at least as good
+            ptile, psk, pblocks = C.c_int32(), C.c_int32(), C.c_int32()
+            L.check(self.lib.idb_gemm_plan(C.byref(d), C.byref(ptile), C.byref(psk), C.byref(pblocks)), "idb_gemm_plan")
+            if psk.value > 1 or gn_stats_always:      # gn_stats_always: tests of the library's extra-statistics-launch path
+                gn_part = self.arena.alloc((batch * (oh * ow // 64) * gn_stats * 2,), torch.float32)
+                d.gn_partials, d.gn_groups = gn_part.data_ptr(), gn_stats
         d.counters, d.counters_len = self._counters.data_ptr(), self._counters.numel()
         need = self.lib.idb_gemm_workspace_bytes(C.byref(d))
         ws = self._workspace(need) if need else None
@@ -387,6 +399,8 @@ class HipEngine:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         L.check(self.lib.idb_gemm(C.byref(d), _ptr(ws), need, _stream()), "idb_gemm")
+        if gn_part is not None:
+            out._gn = (gn_part, oh * ow // 64, gn_stats)
         if log is not None:
             ev1.record()
             log.append({"tile": tile.value, "split_k": sk.value, "blocks": blocks.value, "m": m, "n": n, "k": k_total,
@@ -406,10 +420,18 @@ class HipEngine:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("GroupNorm workspace would grow during graph capture")
             self._gn_ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
+        pin, pin_chunks = None, 0
+        st = getattr(x0, "_gn", None)
+        if st is not None:
+            x0._gn = None
+            if x1 is None and st[1] * 64 == hw and st[2] == groups:
+                pin, pin_chunks = st[0], st[1]           # statistics produced by the GEMM that wrote x0
         L.check(self.lib.idb_groupnorm(x0.data_ptr(), c0, _ptr(x1), c1, batch, hw, groups, eps, gamma.data_ptr(),
                                        beta.data_ptr(), int(silu), out.data_ptr(), self.dt, self._gn_ws.data_ptr(),
                                        self._gn_ws.numel(), _ptr(self._gn_sync), 0 if self._gn_sync is None else self._gn_sync.numel(),
-                                       _stream()), "idb_groupnorm")
+                                       _ptr(pin), pin_chunks, _stream()), "idb_groupnorm")
+        if st is not None:
+            self.arena.free(st[0])
         return out
 
     def layernorm(self, x, rows, c, gamma, beta) -> torch.Tensor:
@@ -431,12 +453,14 @@ class HipEngine:
     # ------------------------------------------------------------------------------------
     # UNet
     # ------------------------------------------------------------------------------------
-    def _resnet(self, name, xa, ca, xb, cb, cout, batch, h, w_, sbias, eps, groups=None) -> torch.Tensor:
+    def _resnet(self, name, xa, ca, xb, cb, cout, batch, h, w_, sbias, eps, groups=None, out_stats: bool = False) -> torch.Tensor:
         W = self.w
         cin = ca + cb
         n1 = self.groupnorm(xa, ca, xb, cb, batch, h * w_, W[f"{name}.gn1.g"], W[f"{name}.gn1.b"], eps, True, groups)
         sb = None if sbias is None else (sbias[0], sbias[1] + self.tproj_off[name], sbias[2])
-        h1 = self.gemm([(n1, cin, 9, h, w_, 0)], W[f"{name}.conv1.w"], cout, batch, h, w_, bias=W[f"{name}.conv1.b"], sbias=sb)
+        G = groups or self.ucfg.norm_num_groups
+        h1 = self.gemm([(n1, cin, 9, h, w_, 0)], W[f"{name}.conv1.w"], cout, batch, h, w_, bias=W[f"{name}.conv1.b"], sbias=sb,
+                       gn_stats=G)                       # norm2 consumes h1 next
         self.arena.free(n1)
         n2 = self.groupnorm(h1, cout, None, 0, batch, h * w_, W[f"{name}.gn2.g"], W[f"{name}.gn2.b"], eps, True, groups)
         self.arena.free(h1)
@@ -444,11 +468,11 @@ class HipEngine:
             srcs = [(n2, cout, 9, h, w_, 0), (xa, ca, 1, h, w_, 0)]
             if xb is not None:
                 srcs.append((xb, cb, 1, h, w_, 0))
-            out = self.gemm(srcs, W[f"{name}.conv2.w"], cout, batch, h, w_, bias=W[f"{name}.conv2.b"])
+            out = self.gemm(srcs, W[f"{name}.conv2.w"], cout, batch, h, w_, bias=W[f"{name}.conv2.b"], gn_stats=G if out_stats else 0)
         else:
             assert xb is None and ca == cout
             out = self.gemm([(n2, cout, 9, h, w_, 0)], W[f"{name}.conv2.w"], cout, batch, h, w_, bias=W[f"{name}.conv2.b"],
-                            residual=xa)
+                            residual=xa, gn_stats=G if out_stats else 0)
         self.arena.free(n2)
         return out
 
@@ -537,7 +561,11 @@ class HipEngine:
         ch = c0
         for blk in g.down:
             for j, r in enumerate(blk["resnets"]):
-                y = self._resnet(r.name, x, r.cin, None, 0, r.cout, B, h, w_, sbias, eps_n)
+                # the next consumer of y is a non-concatenated GroupNorm (Transformer2DModel.norm or the next resnet's norm1)
+                # unless the block's downsample conv comes first
+                last = j == len(blk["resnets"]) - 1
+                y = self._resnet(r.name, x, r.cin, None, 0, r.cout, B, h, w_, sbias, eps_n,
+                                 out_stats=bool(blk["attns"]) or not (last and blk["down"]))
                 self._free(x)
                 x, ch = y, r.cout
                 if blk["attns"]:
@@ -548,13 +576,13 @@ class HipEngine:
                 self._pinned.add(x.data_ptr())
             if blk["down"]:
                 y = self.gemm([(x, ch, 9, h, w_, 0)], W[blk["down"] + ".w"], ch, B, h // 2, w_ // 2,
-                              bias=W[blk["down"] + ".b"], stride=2)
+                              bias=W[blk["down"] + ".b"], stride=2, gn_stats=cfg.norm_num_groups)   # next: a resnet's norm1
                 h, w_ = h // 2, w_ // 2
                 x = y
                 skips.append((x, ch))
                 self._pinned.add(x.data_ptr())
         m = g.mid
-        y = self._resnet(m["resnets"][0].name, x, ch, None, 0, ch, B, h, w_, sbias, eps_n)
+        y = self._resnet(m["resnets"][0].name, x, ch, None, 0, ch, B, h, w_, sbias, eps_n, out_stats=True)
         x = y                                           # previous x is the last skip: stays pinned
         y = self._transformer(m["attn"], x, B, h, w_, kv[m["attn"].name], n_ctx)
         self._free(x)
@@ -566,7 +594,7 @@ class HipEngine:
             for j, r in enumerate(blk["resnets"]):
                 sk, sc = skips.pop()
                 assert sc == r.skip_channels and ch + sc == r.cin
-                y = self._resnet(r.name, x, ch, sk, sc, r.cout, B, h, w_, sbias, eps_n)
+                y = self._resnet(r.name, x, ch, sk, sc, r.cout, B, h, w_, sbias, eps_n, out_stats=bool(blk["attns"]))
                 self._pinned.discard(sk.data_ptr())
                 self.arena.free(sk)
                 self._free(x)

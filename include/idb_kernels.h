@@ -88,6 +88,12 @@ typedef struct {
                                  flags bit 4: a split-K launch then reduces inside the GEMM (the last-arriving workgroup of a
                                  tile sums the slabs in fixed order and runs the epilogue; counters are left zero) */
     int32_t counters_len;
+    float* gn_partials;       /* optional out: per-(sample, 64-row block, group) {sum, sum of squares} of the ROUNDED output, fp32
+                                 [batch][out_h*out_w/64][gn_groups][2] — the first pass of the nn.GroupNorm that consumes `out`
+                                 (idb_groupnorm's partials_in), produced by the split-K reduce launch when there is one, by an extra
+                                 statistics launch otherwise.  Needs out_h*out_w % 64 == 0, out_h*out_w <= 4096, n % gn_groups == 0,
+                                 operand-dtype output, no GEGLU */
+    int32_t gn_groups;
     int32_t pad_mode;         /* taps=9 sources — 0: zero padding 1 on every side (nn.Conv2d padding=1); 1: padding on the
                                  bottom/right only, i.e. F.pad(x, (0,1,0,1)) + padding=0, the stride-2 Downsample2D of the VAE
                                  encoder (diffusers downsampling.py; AutoencoderKL.encode at train_ID-Booth.py:1001) */
@@ -123,12 +129,14 @@ int idb_lora_merge(const float* w, const float* lora_a, const float* lora_b, voi
  * zero): when given, and the whole grid is resident on the chip at once (small batches), the two
  * passes run as ONE launch whose workgroups hand their partial sums over through these counters;
  * NULL selects the two-launch form.  One array may serve every call on the same stream.
+ * partials_in: optional statistics already produced by idb_gemm (idb_gemm_desc.gn_partials) for x0 (then x1 must be NULL);
+ * partials_chunks = hw / 64.  Only the normalise pass is launched.
  * ------------------------------------------------------------------------------------------ */
 size_t idb_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups);
 int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw,
                   int32_t groups, float eps, const float* gamma, const float* beta, int32_t silu,
                   void* out, int32_t dtype, void* workspace, size_t workspace_bytes, int32_t* sync,
-                  int32_t sync_len, void* stream);
+                  int32_t sync_len, const float* partials_in, int32_t partials_chunks, void* stream);
 int idb_layernorm(const void* x, void* out, int64_t rows, int32_t c, float eps, const float* gamma,
                   const float* beta, int32_t dtype, void* stream);
 

@@ -225,6 +225,40 @@ def test_groupnorm(eng, b, hw, c0, c1, silu, eps):
     _check(out.view(b, hw, c).permute(0, 2, 1), ref, _tol(eng), "groupnorm")
 
 
+@pytest.mark.parametrize("b,side,cin,cout,split_k,res", [(2, 16, 128, 320, 4, True), (2, 32, 64, 640, 8, False), (1, 8, 256, 1280, 16, True),
+                                                         (2, 16, 128, 320, 1, True), (3, 8, 64, 128, 3, False), (2, 64, 64, 320, 2, False)])
+def test_groupnorm_statistics_from_the_gemm(eng, b, side, cin, cout, split_k, res):
+    """idb_gemm_desc.gn_partials: the conv's split-K reduce launch (or, without a split, an extra statistics launch) emits the
+    per-(sample, 64-row block, group) sums of its rounded output; idb_groupnorm(partials_in) then only normalises.  The result
+    must agree with the ordinary two-pass GroupNorm of the same tensor (same rounded inputs; summation order differs) and with
+    torch."""
+    g = torch.Generator().manual_seed(17)
+    hw = side * side
+    x = torch.randn(b * hw, cin, generator=g).to(DEV).to(eng.tdt)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=g).to(DEV)
+    resid = torch.randn(b * hw, cout, generator=g).to(DEV).to(eng.tdt) if res else None
+    gamma, beta = _rand((cout,), 32) * 0.2 + 1, _rand((cout,), 33) * 0.1
+    wp = eng._pack_conv(w)
+    eng.arena.reset()
+    y = eng.gemm([(x, cin, 9, side, side, 0)], wp, cout, b, side, side, bias=bias, residual=resid, split_k=split_k, gn_stats=32)
+    if split_k == 1:                     # no reduce launch to ride on: the engine does not ask; the library would add a launch
+        assert getattr(y, "_gn", None) is None
+        eng.arena.free(y)
+        y = eng.gemm([(x, cin, 9, side, side, 0)], wp, cout, b, side, side, bias=bias, residual=resid, split_k=1, gn_stats=32,
+                     gn_stats_always=True)
+    assert getattr(y, "_gn", None) is not None and y._gn[1] == hw // 64
+    y_plain = eng.gemm([(x, cin, 9, side, side, 0)], wp, cout, b, side, side, bias=bias, residual=resid, split_k=split_k)
+    fused = eng.groupnorm(y, cout, None, 0, b, hw, gamma, beta, 1e-5, True, groups=32)
+    assert y._gn is None
+    plain = eng.groupnorm(y_plain, cout, None, 0, b, hw, gamma, beta, 1e-5, True, groups=32)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_plain)                                   # the reduce+statistics kernel writes the same tensor
+    ref = F.silu(F.group_norm(y_plain.float().view(b, hw, cout).permute(0, 2, 1), 32, gamma, beta, 1e-5))
+    _check(fused.view(b, hw, cout).permute(0, 2, 1), ref, _tol(eng), "groupnorm(statistics from the GEMM)")
+    assert (fused.float() - plain.float()).abs().max().item() <= _tol(eng) * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("b,hw,c0,c1", [(2, 4096, 320, 0), (2, 4096, 640, 320), (2, 1024, 1280, 640), (2, 256, 1280, 1280), (1, 4096, 512, 0)])
 def test_groupnorm_single_launch_handoff(eng, b, hw, c0, c1):
     """Opt-in single-launch form (workgroups hand partial sums over through self-resetting counters): many launches back to
@@ -240,7 +274,8 @@ def test_groupnorm_single_launch_handoff(eng, b, hw, c0, c1):
         out = torch.empty((b * hw, c), dtype=eng.tdt, device=DEV)
         L.check(eng.lib.idb_groupnorm(x0.data_ptr(), c0, x1.data_ptr() if c1 else None, c1, b, hw, 32, 1e-5, gamma.data_ptr(),
                                       beta.data_ptr(), 1, out.data_ptr(), eng.dt, eng._gn_ws.data_ptr(), eng._gn_ws.numel(),
-                                      None if counters is None else counters.data_ptr(), 0 if counters is None else counters.numel(), st))
+                                      None if counters is None else counters.data_ptr(), 0 if counters is None else counters.numel(),
+                                      None, 0, st))
         return out
 
     runs = []
