@@ -7,18 +7,21 @@
 //
 // Design (MI355X):
 //   * NHWC activations: one K-step (64 channels of one tap) of an im2col row is ONE contiguous
-//     128-byte line, so both operands stream HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA,
-//     16 B/lane, no VGPR staging); zero padding = lanes pointed at a zero page.
+//     128-byte line, so both operands stream HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (LDS-DMA,
+//     16 B/lane, no VGPR staging); zero padding = out-of-range buffer offsets (hardware zero fill).
 //   * LDS tile rows are 128 B; chunk c of row r is stored at chunk position c ^ (r & 7) (swizzle
 //     applied on the SOURCE address, LDS-DMA destinations are lane-linear) so every ds_read_b128
 //     fragment read is bank-conflict free.
 //   * v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate.  The weight fragment is the MFMA A operand
 //     and the activation fragment the B operand, so each lane ends up with 4 CONSECUTIVE output
 //     channels of one pixel -> 8-byte (bf16) / 16-byte (fp32) epilogue accesses.
-//   * double-buffered LDS, next tile's DMA issued before the current tile's MFMAs, one barrier
-//     per K-step; XCD-aware bijective block remap so blocks sharing an activation tile share an L2.
-//   * small-M layers (8x8 / 16x16 levels at batch 1) use split-K with fp32 slabs + a fused
-//     reduce/epilogue kernel (deterministic, no atomics).
+//   * LDS ring of 2 stages (two workgroups per CU hide each other's latency) or 3 stages (a lone
+//     workgroup per CU: two K-steps in flight), 8 waves per workgroup by default, next stage's DMA
+//     issued before the current stage's MFMAs, counted vmcnt, one barrier per K-step; XCD-aware
+//     bijective block remaps (runs of tiles per XCD, or one K-slice per XCD for split-K grids).
+//   * grids smaller than the chip (the whole batch-1 UNet) use split-K sized to one workgroup per
+//     CU, fp32 slabs + a reduce/epilogue launch (deterministic, no atomics) that can also emit the
+//     first GroupNorm pass of its output.
 #include "idb_common.h"
 #include <stdlib.h>
 

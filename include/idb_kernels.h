@@ -80,7 +80,7 @@ typedef struct {
     int32_t out_dtype;        /* IDB_BF16/IDB_F16 (== dtype) or IDB_F32 */
     int32_t out_ld;           /* elements between output rows */
     int32_t split_k;          /* 0 = library heuristic, >=1 explicit */
-    int32_t tile;             /* 0 = heuristic; else 1..5 selects a tile config (see idb_gemm_plan) */
+    int32_t tile;             /* 0 = heuristic; else a tile config id as idb_gemm_plan reports it (tests and measurements) */
     float out_scale;          /* multiplies the accumulator before bias (0 => 1.0) */
     int32_t flags;            /* profiling/testing only — bit 0: skip the split-K reduce launch (`out` not written); bit 1: skip the epilogue stores; bit 2: force the direct (non-LDS-staged) epilogue; bit 3: force the two-launch split-K reduce; bit 4: in-kernel split-K reduce (default: separate reduce launch, which measured faster) */
     int32_t act;              /* 0 none, 1 exact GELU applied to (acc*scale + bias) (CLIP MLP fc1); not with residual/GEGLU */
