@@ -24,7 +24,7 @@ EXPORTS = [
     "idb_attention", "idb_embed_tokens", "idb_softmax_rows",
     "idb_timestep_sinusoid", "idb_linear_f32", "idb_conv_in",
     "idb_cfg_ddpm_step", "idb_postprocess",
-    "idb_nhwc_to_nchw_f32", "idb_f32_nhwc_to_nchw", "idb_cast_f32", "idb_vae_sample",
+    "idb_nhwc_to_nchw_f32", "idb_f32_nhwc_to_nchw", "idb_cast_f32", "idb_vae_sample", "idb_warp_affine_u8",
 ]
 
 
@@ -87,6 +87,7 @@ def load() -> C.CDLL:
         "idb_f32_nhwc_to_nchw": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "idb_cast_f32": (C.c_int, [vp, vp, i64, i32, vp]),
         "idb_vae_sample": (C.c_int, [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp]),
+        "idb_warp_affine_u8": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing

@@ -188,6 +188,33 @@ __global__ __launch_bounds__(256) void cfg_ddpm_kernel(const float* __restrict__
 }
 
 // K10
+// cv2.warpAffine, 8-bit, INTER_LINEAR, BORDER_CONSTANT: one thread per destination pixel (all channels)
+__global__ __launch_bounds__(256) void warp_affine_u8_kernel(const unsigned char* __restrict__ src, int batch, int H, int W, int C,
+                                                             const double* __restrict__ minv, unsigned char* __restrict__ dst,
+                                                             int oh, int ow, int border) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)batch * oh * ow) return;
+    const int x = (int)(i % ow), y = (int)((i / ow) % oh);
+    const int b = (int)(i / ((long long)ow * oh));
+    const double* m = minv + (long long)b * 6;
+    // OpenCV: adelta/bdelta and X0/Y0 are rounded separately (saturate_cast<int> = round half to even), then added
+    const int adelta = __double2int_rn(m[0] * x * 1024.0), bdelta = __double2int_rn(m[3] * x * 1024.0);
+    const int X0 = __double2int_rn((m[1] * y + m[2]) * 1024.0) + 16, Y0 = __double2int_rn((m[4] * y + m[5]) * 1024.0) + 16;
+    const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    const unsigned char* img = src + (long long)b * H * W * C;
+    const bool y0 = sy >= 0 && sy < H, y1 = sy + 1 >= 0 && sy + 1 < H, x0 = sx >= 0 && sx < W, x1 = sx + 1 >= 0 && sx + 1 < W;
+    unsigned char* o = dst + i * C;
+    for (int c = 0; c < C; ++c) {
+        const int p00 = (y0 && x0) ? img[((long long)sy * W + sx) * C + c] : border;
+        const int p01 = (y0 && x1) ? img[((long long)sy * W + sx + 1) * C + c] : border;
+        const int p10 = (y1 && x0) ? img[((long long)(sy + 1) * W + sx) * C + c] : border;
+        const int p11 = (y1 && x1) ? img[((long long)(sy + 1) * W + sx + 1) * C + c] : border;
+        o[c] = (unsigned char)((w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11 + (1 << 14)) >> 15);
+    }
+}
+
 // DiagonalGaussianDistribution.sample()/.mode() * scaling_factor: moments NHWC [B][HW][2C] -> latents NCHW [B][C][HW]
 __global__ __launch_bounds__(256) void vae_sample_kernel(const float* __restrict__ moments, const float* __restrict__ noise,
                                                          float scale, float* __restrict__ latents, float* __restrict__ mean_out,
@@ -339,6 +366,17 @@ extern "C" int idb_cfg_ddpm_step(const float* eps, float* latents, const float* 
     hipLaunchKernelGGL(cfg_ddpm_kernel, dim3(blocks_for((long long)batch * channels * hw)), dim3(256), 0, (hipStream_t)stream,
                        eps, latents, noise, coef, x0_out, batch, channels, hw, cfg, prediction_type);
     IDB_CHECK_LAUNCH("idb_cfg_ddpm_step");
+    return IDB_OK;
+}
+
+extern "C" int idb_warp_affine_u8(const uint8_t* src, int32_t batch, int32_t h, int32_t w, int32_t channels, const double* m_inv,
+                                  uint8_t* dst, int32_t out_h, int32_t out_w, int32_t border_value, void* stream) {
+    IDB_REQUIRE(src && m_inv && dst && batch > 0 && h > 0 && w > 0 && channels > 0 && channels <= 4 && out_h > 0 && out_w > 0,
+                "idb_warp_affine_u8: bad args");
+    IDB_REQUIRE(h < (1 << 20) && w < (1 << 20) && border_value >= 0 && border_value <= 255, "idb_warp_affine_u8: size/border out of range");
+    hipLaunchKernelGGL(warp_affine_u8_kernel, dim3(blocks_for((long long)batch * out_h * out_w)), dim3(256), 0, (hipStream_t)stream, src,
+                       batch, h, w, channels, m_inv, dst, out_h, out_w, border_value);
+    IDB_CHECK_LAUNCH("idb_warp_affine_u8");
     return IDB_OK;
 }
 

@@ -202,6 +202,15 @@ int idb_cast_f32(const float* x, void* out, int64_t count, int32_t dtype, void* 
  * output of the encoder's conv_out with quant_conv folded in; noise: NCHW fp32 [batch][channels][hw] or NULL (mode);
  * latents, and optional mean / logvar (clamped to [-30, 20]) outputs: NCHW fp32.
  * ------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------
+ * Face align-and-crop warp: cv2.warpAffine(img, M, (out_w, out_h), borderValue) for 8-bit images with
+ * OpenCV's defaults (INTER_LINEAR, BORDER_CONSTANT) — utils/detect_align_crop_data.py:180.  src: uint8 [batch][h][w][channels];
+ * m_inv: [batch][6] doubles, the INVERSE of each 2x3 matrix (cv::invertAffineTransform, computed on the host in double);
+ * coordinates in 10-bit fixed point with a 5-bit sub-pixel fraction, 15-bit integer tap weights: integer-exact.
+ * ------------------------------------------------------------------------------------------ */
+int idb_warp_affine_u8(const uint8_t* src, int32_t batch, int32_t h, int32_t w, int32_t channels, const double* m_inv,
+                       uint8_t* dst, int32_t out_h, int32_t out_w, int32_t border_value, void* stream);
+
 int idb_vae_sample(const float* moments, const float* noise, float scale, float* latents, float* mean_out,
                    float* logvar_out, int32_t batch, int32_t channels, int32_t hw, void* stream);
 
