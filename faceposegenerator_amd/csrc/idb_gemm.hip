@@ -1114,9 +1114,10 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         //    (M = 128) the 64x128 ring-3 tile with the same rule;
         //  * short K: 64-row ring-3 tiles, split only for tiny grids (the reduce launch costs more than a short K loop).
         const bool short_k = pl->ktiles <= 10;
+        static const int plan_ab_early = [] { const char* e = getenv("IDB_GEMM_PLAN_AB"); return e ? atoi(e) : 0; }();
         if (d->n <= 32) tile = 5;
         else if (d->geglu && blocks_big >= 256) tile = pl->ktiles >= 16 ? 2 : 9;   // N = 8C, no split-K: 128-row (persistent form for K >= 1024)
-        else if (blocks_big >= 512) tile = n160 ? 8 : 9;
+        else if (blocks_big >= (plan_ab_early & 2 ? 512 : 384)) tile = n160 ? 8 : 9;   // measured at batch 3 (384 workgroups): +6 % over the 64-row tiles; at 256 (batch 2): -1.4 %
         else if (!d->geglu && pl->ktiles >= 32 && blocks_big < 256) {
             int sk = (int)(256 / blocks_big);
             const int cap = pl->ktiles / 8;
