@@ -7,7 +7,7 @@ from faceposegenerator_amd.engine import HipEngine
 from tools.bench_kernels import timeit
 eng = HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, "cuda:0", "bf16")
 dev = eng.device
-for be in (32, 2):
+for be in (32, 16, 2):
     for side, c in ((64, 320), (32, 640), (16, 1280)):
         m = be * side * side
         x = torch.randn(m, c, device=dev).to(eng.tdt)
@@ -15,7 +15,7 @@ for be in (32, 2):
         b = torch.randn(8 * c, device=dev)
         fl = 2.0 * m * 8 * c * c
         res = []
-        for tile in (2, 9, 42, 0):
+        for tile in (2, 9, 19, 7, 17, 4, 14, 42, 0):
             def run():
                 eng.arena.reset()
                 eng.gemm([(x, c, 1, 1, 1, 0)], w, 8 * c, m, 1, 1, bias=b, geglu=True, tile=tile)
