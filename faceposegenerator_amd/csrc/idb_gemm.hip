@@ -36,6 +36,7 @@ struct GemmParams {
     int M, N, HW, OW, stride, pad;
     unsigned w_row_bytes, w_bytes;
     int ktiles, kt_per_split, splitk;
+    int slab_swc;   // 0: split-K slabs are [z][M][N] row-major; else [z][M/64][N/swc][64][swc] blocks = the windows of idb_splitk_reduce_gn_kernel
     int xcd_mode;   // 0: tiles dealt to XCDs in runs, K-split on grid z; 1/2: one K-slice per XCD (group), see idb_gemm_kernel
     const char* w;
     const float* bias;
@@ -180,7 +181,15 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 const int n = n0 + (wn * NF + j) * 16 + fg * 4;
-                if (vec4 && n + 3 < p.N) {
+                if (p.slab_swc) {
+                    // blocked slab: the reduce + GroupNorm-statistics kernel then reads each of its 64 x swc windows as ONE
+                    // contiguous run (row-major windows of 40-64 channels are 160-256-byte pieces at a row stride)
+                    if (n < p.N) {
+                        const int sl = n / p.slab_swc;
+                        float* blk = p.partial + ((((long long)kz * (p.M >> 6) + (m >> 6)) * (p.N / p.slab_swc) + sl) * 64 + (m & 63)) * p.slab_swc;
+                        *(f32x4*)(blk + (n - sl * p.slab_swc)) = acc[i][j];
+                    }
+                } else if (vec4 && n + 3 < p.N) {
                     *(f32x4*)(dst + n) = acc[i][j];
                 } else {
 #pragma unroll
@@ -960,7 +969,8 @@ __global__ __launch_bounds__(1024) void idb_splitk_reduce_gn_kernel(const float*
     if (res) r4 = *(const V4*)(res + (long long)m * out_ld + n);
     if (bias) bi = *(const f32x4*)(bias + n);
     if (sbias) sbv = *(const f32x4*)(sbias + (long long)(m / HW) * sbias_ld + n);
-    const float* src = partial + (long long)m * N + n;
+    // slabs in the blocked layout GemmParams::slab_swc describes: this workgroup's window is one contiguous run per slab
+    const float* src = partial + (((long long)blockIdx.x * gridDim.y + blockIdx.y) * 64 + row) * swc + col * 4;
     const long long slab = (long long)M * N;
     f32x4 v = zero;
     for (int z0 = 0; z0 < splitk; z0 += 8) {
@@ -1266,6 +1276,18 @@ int launch_tile_pl(const GemmParams& p, const Plan& pl, hipStream_t st) {
     return IDB_OK;
 }
 
+// slice width of idb_splitk_reduce_gn_kernel: the largest multiple of lcm(group width, 4) that is <= 64 and divides n (one thread
+// per row and 4 channels: 64 * swc / 4 <= 1024 threads); 0 if there is none
+inline int gn_reduce_slice(int n, int groups) {
+    const int cpg = n / groups;
+    int base = cpg;
+    while (base % 4) base += cpg;
+    int swc = 0;
+    for (int c = base; c <= 64; c += base)
+        if (n % c == 0) swc = c;
+    return swc;
+}
+
 template <typename T>
 int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
     int rc;
@@ -1303,16 +1325,9 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
     const bool vec_ok = d->n % 4 == 0 && d->out_ld % 4 == 0 && idb_aligned16(p.partial) && (!p.bias || idb_aligned16(p.bias)) &&
                         (!p.sbias || (idb_aligned16(p.sbias) && p.sbias_ld % 4 == 0)) && (!p.res || ((uintptr_t)p.res & 7) == 0) &&
                         ((uintptr_t)p.out & 15) == 0;
-    if (d->gn_partials && vec_ok && !p.out_f32) {
-        // reduce + first GroupNorm pass in one launch: slice width = largest multiple of lcm(group width, 4) that is <= 64 and
-        // divides n (one thread per row and 4 channels: 64 * swc / 4 <= 1024 threads)
-        const int cpg = d->n / d->gn_groups;
-        int base = cpg;
-        while (base % 4) base += cpg;
-        int swc = 0;
-        for (int c = base; c <= 64; c += base)
-            if (d->n % c == 0) swc = c;
-        if (swc > 0 && pl.M % 64 == 0) {
+    if (p.slab_swc) {
+        {
+            const int swc = p.slab_swc;       // chosen in idb_gemm together with the blocked slab layout the GEMM has just written
             hipLaunchKernelGGL((idb_splitk_reduce_gn_kernel<T>), dim3(pl.M / 64, d->n / swc), dim3(16 * swc), 0, st, p.partial, pl.splitk,
                                pl.M, d->n, p.HW, p.scale, p.bias, p.sbias, p.sbias_ld, (const T*)p.res, (T*)p.out, p.out_ld,
                                d->gn_partials, d->gn_groups, swc);
@@ -1416,6 +1431,14 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
         p.counters = fused_reduce ? d->counters : nullptr;
         p.lds_epi = (pl.tile / 10 != 4 && !p.out_f32 && (pl.splitk == 1 || fused_reduce) && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&
                      (!d->residual || idb_aligned16(d->residual))) ? 1 : 0;
+    }
+    p.slab_swc = 0;
+    if (d->gn_partials && pl.splitk > 1 && !p.counters && !(d->flags & 1) && !p.out_f32 && pl.M % 64 == 0) {
+        // the reduce launch will be idb_splitk_reduce_gn_kernel: same conditions and slice width as launch_all computes
+        const bool vec_ok = d->n % 4 == 0 && d->out_ld % 4 == 0 && idb_aligned16(p.partial) && (!p.bias || idb_aligned16(p.bias)) &&
+                            (!p.sbias || (idb_aligned16(p.sbias) && p.sbias_ld % 4 == 0)) && (!p.res || ((uintptr_t)p.res & 7) == 0) &&
+                            ((uintptr_t)p.out & 15) == 0;
+        if (vec_ok) p.slab_swc = gn_reduce_slice(d->n, d->gn_groups);
     }
     hipStream_t st = (hipStream_t)stream;
     return d->dtype == IDB_BF16 ? launch_all<__bf16>(d, p, pl, st) : launch_all<_Float16>(d, p, pl, st);
