@@ -17,7 +17,7 @@ IDB_MAX_SRC = 4
 
 # every symbol include/idb_kernels.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "idb_version", "idb_last_error", "idb_device_check",
+    "idb_version", "idb_launch_count", "idb_last_error", "idb_device_check",
     "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm",
     "idb_pack_conv_weight", "idb_pack_matrix", "idb_lora_merge",
     "idb_groupnorm_workspace_bytes", "idb_groupnorm", "idb_layernorm",
@@ -64,6 +64,7 @@ def load() -> C.CDLL:
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
     sig = {
         "idb_version": (C.c_int, []),
+        "idb_launch_count": (C.c_uint64, []),
         "idb_last_error": (C.c_char_p, []),
         "idb_device_check": (C.c_int, [C.c_int]),
         "idb_gemm_workspace_bytes": (sz, [C.POINTER(GemmDesc)]),

@@ -94,8 +94,11 @@ const void* idb_zero_page(void);   // >= 256 zero bytes in device memory (paddin
         }                                       \
     } while (0)
 
+extern unsigned long long idb_launch_counter;   // idb_misc.hip; read through idb_launch_count()
+
 #define IDB_CHECK_LAUNCH(name)                                                     \
     do {                                                                           \
+        __atomic_fetch_add(&idb_launch_counter, 1ull, __ATOMIC_RELAXED);           \
         hipError_t e_ = hipGetLastError();                                         \
         if (e_ != hipSuccess) {                                                    \
             idb_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \

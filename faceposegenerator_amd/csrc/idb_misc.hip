@@ -18,7 +18,10 @@ void idb_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* idb_last_error(void) { return g_err; }
-extern "C" int idb_version(void) { return 100; }
+extern "C" int idb_version(void) { return 200; }
+
+unsigned long long idb_launch_counter = 0;
+extern "C" uint64_t idb_launch_count(void) { return __atomic_load_n(&idb_launch_counter, __ATOMIC_RELAXED); }
 
 const void* idb_zero_page(void) {
     // one zero page per device; immutable after creation (the only process-global state)

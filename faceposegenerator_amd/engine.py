@@ -110,6 +110,7 @@ class HipEngine:
         self.arena = Arena(self.device)
         self._ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
         self._gn_ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self._retired: List[torch.Tensor] = []      # outgrown workspaces that captured graphs may still reference
         self._counters = torch.zeros(1 << 16, dtype=torch.int32, device=self.device)   # split-K tickets (self-resetting)
         # GroupNorm single-launch hand-off counters (self-resetting); opt-in: measured slower than two launches (idb_norm.hip)
         self._gn_sync = torch.zeros(1 << 14, dtype=torch.int32, device=self.device) if os.environ.get("IDB_GN_SYNC") == "1" else None
@@ -121,6 +122,8 @@ class HipEngine:
         self.tproj_total = 0
         self._pinned: set = set()
         self.launch_log: Optional[list] = None
+        self.last_forward_launches = 0
+        self.taps: Optional[dict] = None      # tests: {module name: fp32 copy [B*h*w, C] of the block's output} (eager runs only)
         self.lora_loaded = False
         if unet_sd is not None:
             self._pack_unet(unet_sd)
@@ -287,8 +290,7 @@ class HipEngine:
             n_pairs = sum(1 for k in lora if k.endswith(".lora_A.weight"))
             if used != n_pairs:
                 raise ValueError(f"LoRA file has {n_pairs} adapter pairs but {used} matched UNet attention projections")
-        self.lora_loaded = lora is not None
-        torch.cuda.synchronize(self.device)
+        self.lora_loaded = lora is not None      # stream-ordered: the next launch on this stream sees the merged weights
 
     def _pack_vae(self, sd: SD) -> None:
         w, g = self.w, self.vgraph
@@ -354,6 +356,7 @@ class HipEngine:
         if nbytes > self._ws.numel():
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("split-K workspace would grow during graph capture; run one eager warm-up first")
+            self._retired.append(self._ws)      # captured graphs hold the old address: keep it alive (and private to them)
             self._ws = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=self.device)
         return self._ws
 
@@ -419,6 +422,7 @@ class HipEngine:
         if need > self._gn_ws.numel():
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("GroupNorm workspace would grow during graph capture")
+            self._retired.append(self._gn_ws)   # as _workspace: older graphs keep writing their partials here
             self._gn_ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
         pin, pin_chunks = None, 0
         st = getattr(x0, "_gn", None)
@@ -449,6 +453,11 @@ class HipEngine:
     def _free(self, t: Optional[torch.Tensor]) -> None:
         if t is not None and t.data_ptr() not in self._pinned:
             self.arena.free(t)
+
+    def _tap(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        if self.taps is not None:
+            self.taps[name] = t.float()          # a copy outside the arena
+        return t
 
     # ------------------------------------------------------------------------------------
     # UNet
@@ -552,12 +561,14 @@ class HipEngine:
         b0, cin, h, w_ = lat.shape
         B = b0 * rep
         eps_n = cfg.norm_eps
+        launches0 = self.lib.idb_launch_count()
         c0 = cfg.block_out_channels[0]
         x = self.arena.alloc((B * h * w_, c0), self.tdt)
         L.check(self.lib.idb_conv_in(lat.data_ptr(), W["conv_in.w"].data_ptr(), W["conv_in.b"].data_ptr(), x.data_ptr(),
                                      b0, rep, cin, h, w_, c0, 1.0, None, None, self.dt, _stream()), "idb_conv_in")
         skips: List[Tuple[torch.Tensor, int]] = [(x, c0)]
         self._pinned.add(x.data_ptr())
+        self._tap("conv_in", x)
         ch = c0
         for blk in g.down:
             for j, r in enumerate(blk["resnets"]):
@@ -567,29 +578,29 @@ class HipEngine:
                 y = self._resnet(r.name, x, r.cin, None, 0, r.cout, B, h, w_, sbias, eps_n,
                                  out_stats=bool(blk["attns"]) or not (last and blk["down"]))
                 self._free(x)
-                x, ch = y, r.cout
+                x, ch = self._tap(r.name, y), r.cout
                 if blk["attns"]:
                     y = self._transformer(blk["attns"][j], x, B, h, w_, kv[blk["attns"][j].name], n_ctx)
                     self._free(x)
-                    x = y
+                    x = self._tap(blk["attns"][j].name, y)
                 skips.append((x, ch))
                 self._pinned.add(x.data_ptr())
             if blk["down"]:
                 y = self.gemm([(x, ch, 9, h, w_, 0)], W[blk["down"] + ".w"], ch, B, h // 2, w_ // 2,
                               bias=W[blk["down"] + ".b"], stride=2, gn_stats=cfg.norm_num_groups)   # next: a resnet's norm1
                 h, w_ = h // 2, w_ // 2
-                x = y
+                x = self._tap(blk["down"], y)
                 skips.append((x, ch))
                 self._pinned.add(x.data_ptr())
         m = g.mid
         y = self._resnet(m["resnets"][0].name, x, ch, None, 0, ch, B, h, w_, sbias, eps_n, out_stats=True)
-        x = y                                           # previous x is the last skip: stays pinned
+        x = self._tap(m["resnets"][0].name, y)          # previous x is the last skip: stays pinned
         y = self._transformer(m["attn"], x, B, h, w_, kv[m["attn"].name], n_ctx)
         self._free(x)
-        x = y
+        x = self._tap(m["attn"].name, y)
         y = self._resnet(m["resnets"][1].name, x, ch, None, 0, ch, B, h, w_, sbias, eps_n)
         self._free(x)
-        x = y
+        x = self._tap(m["resnets"][1].name, y)
         for blk in g.up:
             for j, r in enumerate(blk["resnets"]):
                 sk, sc = skips.pop()
@@ -598,15 +609,15 @@ class HipEngine:
                 self._pinned.discard(sk.data_ptr())
                 self.arena.free(sk)
                 self._free(x)
-                x, ch = y, r.cout
+                x, ch = self._tap(r.name, y), r.cout
                 if blk["attns"]:
                     y = self._transformer(blk["attns"][j], x, B, h, w_, kv[blk["attns"][j].name], n_ctx)
                     self._free(x)
-                    x = y
+                    x = self._tap(blk["attns"][j].name, y)
             if blk["up"]:
                 y = self.gemm([(x, ch, 9, h, w_, 1)], W[blk["up"] + ".w"], ch, B, 2 * h, 2 * w_, bias=W[blk["up"] + ".b"])
                 self._free(x)
-                x = y
+                x = self._tap(blk["up"], y)
                 h, w_ = 2 * h, 2 * w_
         assert not skips
         n = self.groupnorm(x, ch, None, 0, B, h * w_, W["conv_norm_out.g"], W["conv_norm_out.b"], eps_n, True)
@@ -614,6 +625,7 @@ class HipEngine:
         eps = self.gemm([(n, ch, 9, h, w_, 0)], W["conv_out.w"], cfg.out_channels, B, h, w_, bias=W["conv_out.b"],
                         out_f32=True, out=eps_out)
         self.arena.free(n)
+        self.last_forward_launches = int(self.lib.idb_launch_count() - launches0)     # kernels of ONE (CFG) UNet forward
         return eps
 
     def unet_forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
@@ -708,8 +720,11 @@ class HipEngine:
             ent = {"ctx": ctx_f32.clone(), "noise": noise.clone(), "coefs": coefs.clone(), "tp": tp.clone(),
                    "lat": torch.empty((B, lc, h, w_), dtype=torch.float32, device=self.device),
                    "eps": torch.empty((rep * B * h * w_, self.ucfg.out_channels), dtype=torch.float32, device=self.device)}
-            hist = torch.empty((2, B, lc, h, w_), dtype=torch.float32, device=self.device) if multistep else None
-            args = (ent["ctx"], ent["noise"], ent["coefs"], ent["tp"], ent["lat"], ent["eps"], steps, rep, n_ctx, vpred, None, hist)
+            # every buffer the captured graph references lives in `ent` (the multistep x0 history too: a local here would go
+            # back to the caching allocator while replays keep writing through its address)
+            ent["hist"] = torch.empty((2, B, lc, h, w_), dtype=torch.float32, device=self.device) if multistep else None
+            args = (ent["ctx"], ent["noise"], ent["coefs"], ent["tp"], ent["lat"], ent["eps"], steps, rep, n_ctx, vpred, None,
+                    ent["hist"])
             self._sample_body(*args)                     # eager warm-up: allocates every arena block, sets func attributes
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()

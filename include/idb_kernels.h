@@ -35,6 +35,9 @@ typedef enum { IDB_BF16 = 0, IDB_F16 = 1, IDB_F32 = 2 } idb_dtype;
 #define IDB_MAX_SRC 4
 
 int idb_version(void);
+/* Number of kernels this library has launched in this process so far (every entry point counts each of its launches, e.g. a
+ * split-K idb_gemm counts the GEMM and its reduce launch).  For launch-count accounting (bench.py, tests); monotonic. */
+uint64_t idb_launch_count(void);
 const char* idb_last_error(void);
 /* 0 iff `device` is a gfx950 part (the only target this library is built for). */
 int idb_device_check(int device);

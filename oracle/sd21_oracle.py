@@ -38,6 +38,17 @@ from faceposegenerator_amd import spec as S
 Tensor = torch.Tensor
 SD = Dict[str, Tensor]
 
+# Error-attribution hook (tests/tools only; None = the plain fp32 restatement).  When set to ``f(kind, tensor) -> tensor`` it is
+# applied at the points where the HIP engine rounds to its operand dtype, so that the CPU oracle can emulate the product's
+# rounding class by class: kind "res" = residual-stream tensors (conv_in / resnet / transformer / down- and up-sample outputs
+# and the h0..h3 stream inside a transformer block), "act" = every other stored activation (norm outputs, conv1 output,
+# q/k/v, attention output, GEGLU product).  Weight rounding is emulated by rounding the state dict before the call.
+ROUND = None
+
+
+def _r(kind: str, t: Tensor) -> Tensor:
+    return t if ROUND is None else ROUND(kind, t)
+
 
 # ----------------------------------------------------------------------------------------
 # embeddings  (diffusers models/embeddings.py: get_timestep_embedding, flip_sin_to_cos=True,
@@ -91,63 +102,66 @@ def merge_lora(sd: SD, lora: SD, scale: float = 1.0) -> SD:
 # ----------------------------------------------------------------------------------------
 def resnet_block(sd: SD, p: str, x: Tensor, temb: Optional[Tensor], groups: int, eps: float) -> Tensor:
     h = F.group_norm(x, groups, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
-    h = F.silu(h)
+    h = _r("act", F.silu(h))
     h = F.conv2d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
     if temb is not None:
         t = F.linear(F.silu(temb), sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"])
         h = h + t[:, :, None, None]
+    h = _r("act", h)
     h = F.group_norm(h, groups, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps)
-    h = F.silu(h)
+    h = _r("act", F.silu(h))
     h = F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
     if (p + ".conv_shortcut.weight") in sd:
         x = F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])
-    return x + h
+    return _r("res", x + h)
 
 
 def attention(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int, lora: Optional[SD]) -> Tensor:
     b, n, c = x.shape
-    q = _linear(sd, p + ".to_q", x, lora)
-    k = _linear(sd, p + ".to_k", ctx, lora)
-    v = _linear(sd, p + ".to_v", ctx, lora)
+    q = _r("act", _linear(sd, p + ".to_q", x, lora))
+    k = _r("act", _linear(sd, p + ".to_k", ctx, lora))
+    v = _r("act", _linear(sd, p + ".to_v", ctx, lora))
     d = c // heads
     q = q.view(b, n, heads, d).transpose(1, 2)
     k = k.view(b, -1, heads, d).transpose(1, 2)
     v = v.view(b, -1, heads, d).transpose(1, 2)
     o = F.scaled_dot_product_attention(q, k, v)          # scale 1/sqrt(d), no mask, no dropout
-    o = o.transpose(1, 2).reshape(b, n, c)
+    o = _r("act", o.transpose(1, 2).reshape(b, n, c))
     return _linear(sd, p + ".to_out.0", o, lora)
 
 
 def transformer_block(sd: SD, p: str, h: Tensor, ctx: Tensor, heads: int, lora: Optional[SD]) -> Tensor:
     c = h.shape[-1]
-    n1 = F.layer_norm(h, (c,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
-    h = attention(sd, p + ".attn1", n1, n1, heads, lora) + h
-    n2 = F.layer_norm(h, (c,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
-    h = attention(sd, p + ".attn2", n2, ctx, heads, lora) + h
-    n3 = F.layer_norm(h, (c,), sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)
+    n1 = _r("act", F.layer_norm(h, (c,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5))
+    h = _r("res", attention(sd, p + ".attn1", n1, n1, heads, lora) + h)
+    n2 = _r("act", F.layer_norm(h, (c,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5))
+    h = _r("res", attention(sd, p + ".attn2", n2, ctx, heads, lora) + h)
+    n3 = _r("act", F.layer_norm(h, (c,), sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5))
     proj = F.linear(n3, sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"])
     val, gate = proj.chunk(2, dim=-1)                    # GEGLU: first half value, second half gate
-    ff = F.linear(val * F.gelu(gate), sd[p + ".ff.net.2.weight"], sd[p + ".ff.net.2.bias"])
-    return ff + h
+    ff = F.linear(_r("act", val * F.gelu(gate)), sd[p + ".ff.net.2.weight"], sd[p + ".ff.net.2.bias"])
+    return _r("res", ff + h)
 
 
 def transformer_2d(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int, groups: int,
                    lora: Optional[SD]) -> Tensor:
     b, c, hh, ww = x.shape
-    h = F.group_norm(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
+    h = _r("act", F.group_norm(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6))
     h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
-    h = F.linear(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    h = _r("res", F.linear(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"]))
     h = transformer_block(sd, p + ".transformer_blocks.0", h, ctx, heads, lora)
     h = F.linear(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
     h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
-    return h + x
+    return _r("res", h + x)
 
 
 def unet_forward(sd: SD, cfg: S.UNetConfig, sample: Tensor, timestep, ctx: Tensor,
                  lora: Optional[SD] = None, taps: Optional[dict] = None) -> Tensor:
     """eps_theta(x_t, t, c).  sample [B,4,H,W] fp32, timestep scalar or [B], ctx [B,L,cross_dim].
 
-    ``taps`` (optional dict) receives named intermediate activations for per-module parity tests.
+    ``taps`` (optional dict) receives named intermediate activations for per-module parity tests; with
+    ``taps["__blocks__"] = True`` also the output of every resnet / transformer / down- / up-sample block under its
+    module name (the per-block error attribution of tests/test_parity_gpu.py).
     """
     g = S.unet_graph(cfg)
     G, eps = cfg.norm_num_groups, cfg.norm_eps
@@ -161,41 +175,47 @@ def unet_forward(sd: SD, cfg: S.UNetConfig, sample: Tensor, timestep, ctx: Tenso
     if taps is not None:
         taps["temb"] = temb
 
-    h = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    def tap(name: str, t: Tensor) -> Tensor:
+        if taps is not None and taps.get("__blocks__"):
+            taps[name] = t
+        return t
+
+    ctx = _r("act", ctx)
+    h = tap("conv_in", _r("res", F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)))
     skips: List[Tensor] = [h]
     for blk in g.down:
         for j, r in enumerate(blk["resnets"]):
-            h = resnet_block(sd, r.name, h, temb, G, eps)
+            h = tap(r.name, resnet_block(sd, r.name, h, temb, G, eps))
             if blk["attns"]:
                 a = blk["attns"][j]
-                h = transformer_2d(sd, a.name, h, ctx, a.heads, G, lora)
+                h = tap(a.name, transformer_2d(sd, a.name, h, ctx, a.heads, G, lora))
             skips.append(h)
         if blk["down"]:
-            h = F.conv2d(h, sd[blk["down"] + ".weight"], sd[blk["down"] + ".bias"], stride=2, padding=1)
+            h = tap(blk["down"], _r("res", F.conv2d(h, sd[blk["down"] + ".weight"], sd[blk["down"] + ".bias"], stride=2, padding=1)))
             skips.append(h)
     if taps is not None:
         taps["down_out"] = h
-    h = resnet_block(sd, g.mid["resnets"][0].name, h, temb, G, eps)
+    h = tap(g.mid["resnets"][0].name, resnet_block(sd, g.mid["resnets"][0].name, h, temb, G, eps))
     a = g.mid["attn"]
-    h = transformer_2d(sd, a.name, h, ctx, a.heads, G, lora)
-    h = resnet_block(sd, g.mid["resnets"][1].name, h, temb, G, eps)
+    h = tap(a.name, transformer_2d(sd, a.name, h, ctx, a.heads, G, lora))
+    h = tap(g.mid["resnets"][1].name, resnet_block(sd, g.mid["resnets"][1].name, h, temb, G, eps))
     if taps is not None:
         taps["mid_out"] = h
     for blk in g.up:
         for j, r in enumerate(blk["resnets"]):
             h = torch.cat([h, skips.pop()], dim=1)
-            h = resnet_block(sd, r.name, h, temb, G, eps)
+            h = tap(r.name, resnet_block(sd, r.name, h, temb, G, eps))
             if blk["attns"]:
                 a = blk["attns"][j]
-                h = transformer_2d(sd, a.name, h, ctx, a.heads, G, lora)
+                h = tap(a.name, transformer_2d(sd, a.name, h, ctx, a.heads, G, lora))
         if blk["up"]:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
-            h = F.conv2d(h, sd[blk["up"] + ".weight"], sd[blk["up"] + ".bias"], padding=1)
+            h = tap(blk["up"], _r("res", F.conv2d(h, sd[blk["up"] + ".weight"], sd[blk["up"] + ".bias"], padding=1)))
     assert not skips
     if taps is not None:
         taps["up_out"] = h
     h = F.group_norm(h, G, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps)
-    h = F.silu(h)
+    h = _r("act", F.silu(h))
     return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
 
 

@@ -4,11 +4,15 @@ weights.  The reference has no tests or fixtures for this path and its arithmeti
 offline, so these vectors pin the ORACLE's behaviour (and, through the GPU tests, the HIP path), not upstream's:
 parity with upstream stays "unpinned" (see the oracle header).
 
-  python tests/golden/make_golden.py [tiny] [full]
+  python tests/golden/make_golden.py [tiny] [full] [config1]
 
 tiny : reduced-width graph, B=2, 16x16 latents, 4 DDPM steps, CFG 5.0, LoRA   -> tiny_trajectory.npz  (seconds)
 full : BASELINE configs[0] = SD-2.1-base shapes, 1 prompt, 64x64 latent, 4 DDPM steps, CFG 5.0, no LoRA
        -> sd21_config0.npz  (~1 minute on 8 cores; the 866 M-parameter weights are regenerated from the seed)
+config1 : BASELINE configs[1] = the headline workload: SD-2.1-base shapes + rank-4 LoRA ("ID_1", synth_lora seed 1),
+       batch 1, 64x64 latent, 30 DDPM steps, CFG 5.0 -> sd21_config1.npz (~10 minutes on 8 cores): latents after each of
+       the 30 steps, final latents, decoded uint8 image, and eps (uncond, cond) of the steps in EPS_STEPS for the
+       teacher-forced per-step comparison
 """
 import os
 import sys
@@ -50,6 +54,9 @@ def run(ucfg, vcfg, useed, vseed, lora_seed, batch, side, steps, gs, fp_names):
     }
 
 
+EPS_STEPS = [0, 4, 9, 14, 19, 24, 29]
+
+
 def main():
     what = sys.argv[1:] or ["tiny", "full"]
     fp = ["conv_in.weight", "mid_block.resnets.0.conv1.weight", "up_blocks.3.attentions.2.transformer_blocks.0.attn2.to_k.weight"]
@@ -63,6 +70,15 @@ def main():
         d["eps_uncond"] = d["eps_uncond"].astype(np.float32)
         np.savez_compressed(os.path.join(HERE, "sd21_config0.npz"), **d)
         print("full: final latents std", d["final_latents"].std(), "image mean", d["image_u8"].mean())
+    if "config1" in what:
+        torch.set_num_threads(os.cpu_count() or 8)
+        d = run(S.SD21_UNET, S.SD21_VAE, 1234, 1235, 1, 1, 64, 30, 5.0, fp)
+        d["eps_steps"] = np.array(EPS_STEPS)
+        d["eps_uncond"] = d["eps_uncond"][EPS_STEPS].astype(np.float32)
+        d["eps_cond"] = d["eps_cond"][EPS_STEPS].astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, "sd21_config1.npz"), **d)
+        print("config1: final latents std", d["final_latents"].std(), "max", np.abs(d["final_latents"]).max(),
+              "image mean", d["image_u8"].mean())
 
 
 if __name__ == "__main__":

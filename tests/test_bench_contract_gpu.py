@@ -23,11 +23,13 @@ def test_bench_json_contract(lib):
         assert k in d, k
     assert d["unit"] == "images/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["dtype"] == "f16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 0.05
+    assert set(d["path"]["stages"]) >= {"sampling_loop_ms", "vae_decode_postprocess_ms", "d2h_uint8_ms"}
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "live_events", "source", "launches_per_cfg_forward_all_kernels"):
         assert k in r, k
+    assert r["launches_per_cfg_forward_all_kernels"] > 100
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):

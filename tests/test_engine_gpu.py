@@ -113,9 +113,10 @@ def test_sampler_matches_oracle(pipe, models, use_graph):
                    width=128, output_type="latent", generator=torch.Generator().manual_seed(0))
         mx, rel = _stats(out.images, ref)
         print(f"[{pipe.dtype_name}] sampler graph={use_graph} call {rep}: latents max-abs {mx:.3e} rel-rms {rel:.3e}")
-        # free-running: each step's eps error is amplified by CFG (|1-g|+|g| = 9) and by c_x0/sqrt(abar_t)
-        # (~1.9 at t=751), so the bound is ~20x the single-forward one; measured: bf16 0.58 / 2.6e-2, f16 0.083 / 3.2e-3
-        assert mx < 20 * TOL[pipe.dtype_name][0] and rel < 4 * TOL[pipe.dtype_name][1]
+        # free-running: each step's eps error is amplified by CFG (|1-g|+|g| = 9) and by c_x0/sqrt(abar_t) (~1.9 at t=751).
+        # Measured on MI355X: bf16 0.58 / 2.6e-2, f16 0.083 / 3.2e-3; bounds = 1.5x the measurement
+        b_mx, b_rel = {"bf16": (0.87, 3.9e-2), "f16": (0.125, 4.8e-3)}[pipe.dtype_name]
+        assert mx < b_mx and rel < b_rel
     pipe.unload_lora_weights()
     del gen
 

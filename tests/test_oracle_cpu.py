@@ -316,3 +316,111 @@ def test_dpm_solver_pp_scheduler_and_oracle():
             assert torch.allclose(cur, ref, rtol=1e-4, atol=1e-4), (pred, order, (cur - ref).abs().max())
     with pytest.raises(ValueError):
         s2.step(x, 5, x)
+
+
+# ---- the oracle's topology, independently of faceposegenerator_amd.spec -------------------------------
+# SURVEY.md Appendix A.1 written out by hand: the module sequence of UNet2DConditionModel for SD-2.1 (block types
+# [CrossAttnDownBlock2D x3, DownBlock2D] / mid / [UpBlock2D, CrossAttnUpBlock2D x3], layers_per_block 2).  "R" = ResnetBlock2D,
+# "T" = Transformer2DModel (heads from the per-level head counts), "D" / "U" = down- / up-sampler conv, "S" = push skip,
+# "C" = concatenate the popped skip.  The oracle (and the product) walk spec.unet_graph; this literal shares nothing with it.
+_A1_LITERAL = (
+    [("S",)] +
+    [("R", "down_blocks.0.resnets.0"), ("T", "down_blocks.0.attentions.0", 0), ("S",),
+     ("R", "down_blocks.0.resnets.1"), ("T", "down_blocks.0.attentions.1", 0), ("S",), ("D", "down_blocks.0.downsamplers.0.conv"), ("S",),
+     ("R", "down_blocks.1.resnets.0"), ("T", "down_blocks.1.attentions.0", 1), ("S",),
+     ("R", "down_blocks.1.resnets.1"), ("T", "down_blocks.1.attentions.1", 1), ("S",), ("D", "down_blocks.1.downsamplers.0.conv"), ("S",),
+     ("R", "down_blocks.2.resnets.0"), ("T", "down_blocks.2.attentions.0", 2), ("S",),
+     ("R", "down_blocks.2.resnets.1"), ("T", "down_blocks.2.attentions.1", 2), ("S",), ("D", "down_blocks.2.downsamplers.0.conv"), ("S",),
+     ("R", "down_blocks.3.resnets.0"), ("S",), ("R", "down_blocks.3.resnets.1"), ("S",),
+     ("R", "mid_block.resnets.0"), ("T", "mid_block.attentions.0", 3), ("R", "mid_block.resnets.1"),
+     ("C",), ("R", "up_blocks.0.resnets.0"), ("C",), ("R", "up_blocks.0.resnets.1"), ("C",), ("R", "up_blocks.0.resnets.2"),
+     ("U", "up_blocks.0.upsamplers.0.conv"),
+     ("C",), ("R", "up_blocks.1.resnets.0"), ("T", "up_blocks.1.attentions.0", 2),
+     ("C",), ("R", "up_blocks.1.resnets.1"), ("T", "up_blocks.1.attentions.1", 2),
+     ("C",), ("R", "up_blocks.1.resnets.2"), ("T", "up_blocks.1.attentions.2", 2), ("U", "up_blocks.1.upsamplers.0.conv"),
+     ("C",), ("R", "up_blocks.2.resnets.0"), ("T", "up_blocks.2.attentions.0", 1),
+     ("C",), ("R", "up_blocks.2.resnets.1"), ("T", "up_blocks.2.attentions.1", 1),
+     ("C",), ("R", "up_blocks.2.resnets.2"), ("T", "up_blocks.2.attentions.2", 1), ("U", "up_blocks.2.upsamplers.0.conv"),
+     ("C",), ("R", "up_blocks.3.resnets.0"), ("T", "up_blocks.3.attentions.0", 0),
+     ("C",), ("R", "up_blocks.3.resnets.1"), ("T", "up_blocks.3.attentions.1", 0),
+     ("C",), ("R", "up_blocks.3.resnets.2"), ("T", "up_blocks.3.attentions.2", 0)])
+
+
+def _unet_forward_from_literal(sd, heads_per_level, time_proj_dim, sample, timestep, ctx, groups=32, eps=1e-5):
+    import torch.nn.functional as F
+    temb = O.timestep_embedding(torch.as_tensor(timestep)[None].expand(sample.shape[0]), time_proj_dim)
+    temb = F.linear(temb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
+    temb = F.linear(F.silu(temb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    h = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    skips = []
+    for op in _A1_LITERAL:
+        if op[0] == "S":
+            skips.append(h)
+        elif op[0] == "C":
+            h = torch.cat([h, skips.pop()], dim=1)
+        elif op[0] == "R":
+            h = O.resnet_block(sd, op[1], h, temb, groups, eps)
+        elif op[0] == "T":
+            h = O.transformer_2d(sd, op[1], h, ctx, heads_per_level[op[2]], groups, None)
+        elif op[0] == "D":
+            h = F.conv2d(h, sd[op[1] + ".weight"], sd[op[1] + ".bias"], stride=2, padding=1)
+        else:
+            h = F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), sd[op[1] + ".weight"], sd[op[1] + ".bias"], padding=1)
+    assert not skips
+    h = F.silu(F.group_norm(h, groups, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps))
+    return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
+def test_oracle_topology_equals_hand_written_appendix_a1(tiny):
+    """The oracle's graph walk (spec.unet_graph, shared with the product) against the hand-written module sequence: same
+    numbers, and the literal consumes every weight tensor of the state dict exactly as named in SURVEY.md Appendix B."""
+    usd, _, _ = tiny
+    g = torch.Generator().manual_seed(21)
+    x, ctx = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 77, 128, generator=g)
+    with torch.no_grad():
+        a = O.unet_forward(usd, S.TINY_UNET, x, 437, ctx)
+        b = _unet_forward_from_literal(usd, S.TINY_UNET.num_heads, S.TINY_UNET.time_proj_dim, x, 437, ctx)
+    assert torch.equal(a, b)
+    named = {op[1] for op in _A1_LITERAL if len(op) > 1}
+    rest = [k for k in usd if not any(k.startswith(m + ".") for m in named)
+            and not k.startswith(("conv_in.", "conv_out.", "conv_norm_out.", "time_embedding."))]
+    assert not rest, f"weights the hand-written topology never touches: {rest[:5]}"
+    assert sum(1 for op in _A1_LITERAL if op[0] == "R") == 22 and sum(1 for op in _A1_LITERAL if op[0] == "T") == 16
+    assert sum(1 for op in _A1_LITERAL if op[0] == "S") == 12 == sum(1 for op in _A1_LITERAL if op[0] == "C")
+
+
+def test_rounding_hook_is_identity_by_default_and_emulates_storage(tiny):
+    usd, _, _ = tiny
+    g = torch.Generator().manual_seed(22)
+    x, ctx = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 77, 128, generator=g)
+    with torch.no_grad():
+        ref = O.unet_forward(usd, S.TINY_UNET, x, 500, ctx)
+        kinds = []
+        O.ROUND = lambda kind, t: (kinds.append(kind), t)[1]
+        try:
+            same = O.unet_forward(usd, S.TINY_UNET, x, 500, ctx)
+            O.ROUND = lambda kind, t: t.half().float()
+            f16 = O.unet_forward(usd, S.TINY_UNET, x, 500, ctx)
+        finally:
+            O.ROUND = None
+    assert torch.equal(ref, same) and set(kinds) == {"act", "res"}
+    rel = ((f16 - ref).norm() / ref.norm()).item()
+    assert 1e-4 < rel < 1e-2
+
+
+def test_config1_golden_fixture_is_wellformed():
+    """BASELINE configs[1] trajectory (30 steps, LoRA): structure + the first step reproduced by the oracle on the reduced checks
+    the CPU suite can afford (scheduler tables and RNG stream; the full trajectory is regenerated by make_golden.py config1)."""
+    gold = np.load(os.path.join(GOLD, "sd21_config1.npz"))
+    assert gold["meta"].tolist() == [1234, 1235, 1, 1, 64, 30, 2024, 0]
+    assert gold["latents_per_step"].shape == (30, 1, 4, 64, 64) and gold["final_latents"].shape == (1, 4, 64, 64)
+    assert np.array_equal(gold["latents_per_step"][-1], gold["final_latents"])
+    assert gold["timesteps"].tolist() == O.ddpm_timesteps(30) == [1 + 33 * k for k in range(29, -1, -1)]
+    assert gold["eps_steps"].tolist() == [0, 4, 9, 14, 19, 24, 29] and gold["eps_cond"].shape == (7, 1, 4, 64, 64)
+    assert gold["image_u8"].shape == (1, 512, 512, 3) and np.isfinite(gold["latents_per_step"]).all()
+    # step 0 is a closed form of the stored eps: latents_0 = ddpm_step(noise_0, eps_guided, noise_1)
+    noise = O.draw_noise(torch.Generator().manual_seed(0), 1, 30, (64, 64))
+    assert np.array_equal(noise.flatten()[:4].numpy(), gold["noise_first4"])
+    e_u, e_c = torch.from_numpy(gold["eps_uncond"][0]), torch.from_numpy(gold["eps_cond"][0])
+    prev, _ = O.ddpm_step(O.ddpm_tables(), O.ddpm_timesteps(30), 958, e_u + 5.0 * (e_c - e_u), noise[0], noise[1])
+    assert np.abs(prev.numpy() - gold["latents_per_step"][0]).max() < 1e-5
