@@ -394,6 +394,7 @@ def main():
 
     fl_unet, fl_vae = 2.0 * S.unet_macs(ucfg, lat_side), 2.0 * S.vae_decode_macs(vcfg, lat_side)
     flops_per_image = 2 * args.ddpm_steps * fl_unet + fl_vae
+    arena_mib = None if fake else round(eng.arena.total_bytes / 2 ** 20, 1)
     default_workload = B == 1 and not args.tiny and args.ddpm_steps == 30 and args.size == 512 and not fake
     config2 = None
     if default_workload and world == 1 and not args.no_config2:
@@ -425,7 +426,7 @@ def main():
         if not fake:
             res["path"] = {"algorithmic_tflop_per_image": round(flops_per_image / 1e12, 3), "tflops": round(path_tflops, 1),
                            "frac_of_mfma_peak": round(path_tflops / PEAK_MFMA_TFLOPS, 4), "gpu_ms_per_step": round(gpu_ms / args.steps, 3),
-                           "load_pack_s": round(t_load, 1), "arena_mib": round(eng.arena.total_bytes / 2 ** 20, 1)}
+                           "load_pack_s": round(t_load, 1), "arena_mib": arena_mib}
             if world == 1:
                 res["path"]["stages"] = stage_times(pipe, eng, pe_d, ne_d, noise, args)
             if config2:
