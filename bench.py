@@ -41,8 +41,10 @@ _TILE_VARIANTS = {0: "idb_gemm_kernel<{},ring2>", 1: "idb_gemm_kernel<{},ring3>"
 
 
 class _TileNames(dict):
-    """idb_gemm_plan tile id -> kernel instance name (id = shape + 10 * variant, see idb_gemm.hip)."""
+    """idb_gemm_plan tile id -> kernel instance name (id = shape + 10 * variant, see idb_gemm.hip); 104 / 105 = idb_hconv_kernel."""
     def __missing__(self, t):
+        if t >= 100:
+            return f"idb_hconv_kernel<128x{32 * (t - 100)},8w>"
         return _TILE_VARIANTS[t // 10].format(_TILE_SHAPES[t % 10])
 
 
@@ -148,13 +150,14 @@ def kernel_roofline(eng, batch, lat_side, n_ctx):
     for e in log:
         e["desc"].flags = 1
         e["ev"] = []
+        e["fn"] = eng.lib.idb_hconv if e.get("hconv") else eng.lib.idb_gemm
     empty = []
     for r in range(REPS + 1):                                            # pass 0 = warm-up, untimed
         for e in log:
             ws, need = e["ws"]
             ev0, ev1 = pair()
             ev0.record()
-            L.check(eng.lib.idb_gemm(C.byref(e["desc"]), None if ws is None else ws.data_ptr(), need, st))
+            L.check(e["fn"](C.byref(e["desc"]), None if ws is None else ws.data_ptr(), need, st))
             ev1.record()
             if r:
                 e["ev"].append((ev0, ev1))
@@ -207,6 +210,8 @@ _KTILES = {1: (4, 5, 2), 2: (4, 4, 2), 3: (2, 5, 2), 4: (1, 2, 4), 5: (4, 1, 2),
 def mangled_gemm_name(tile: int, dtype: str) -> str:
     """Kernel symbol of an idb_gemm_plan tile id as rocprofv3 -M lists it (idb_gemm.hip: kTiles, launch_all)."""
     t = "DF16b" if dtype == "bf16" else "DF16_"
+    if tile >= 100:
+        return f"idb_hconv_kernelI{t}Li{tile - 100}EE"
     mf, nf, wm = _KTILES[tile % 10]
     v = tile // 10
     if v == 3:

@@ -25,317 +25,7 @@
 #include "idb_common.h"
 #include <stdlib.h>
 
-struct GemmSrcK {
-    const char* ptr;
-    unsigned bytes;   // tensor size in bytes = buffer num_records (< 2^31, checked on the host)
-    int C, taps, H, W, up;
-};
-
-struct GemmParams {
-    GemmSrcK src[IDB_MAX_SRC];
-    int M, N, HW, OW, stride, pad;
-    unsigned w_row_bytes, w_bytes;
-    int ktiles, kt_per_split, splitk;
-    int slab_swc;   // 0: split-K slabs are [z][M][N] row-major; else [z][M/64][N/swc][64][swc] blocks = the windows of idb_splitk_reduce_gn_kernel
-    int xcd_mode;   // 0: tiles dealt to XCDs in runs, K-split on grid z; 1/2: one K-slice per XCD (group), see idb_gemm_kernel
-    const char* w;
-    const float* bias;
-    const float* sbias;
-    int sbias_ld;
-    const char* res;
-    void* out;
-    int out_ld, out_f32, geglu;
-    float scale;
-    float* partial;
-    int tiles_n;
-    int dbg_skip_store, lds_epi, act, dbg_loop;   // dbg_loop (profiling): 1 = no MFMA/ds_read, 2 = no operand loads
-    unsigned* counters;   // non-null: in-kernel split-K reduce
-    unsigned out_bytes;   // persistent variant: size of the output tensor (buffer range check drops masked stores)
-};
-
-// voffset of a lane that must read zeros: beyond num_records of every descriptor (all < 2^31), and
-// voffset + soffset cannot wrap, whichever of the two the hardware range check looks at.
-[[maybe_unused]] constexpr unsigned IDB_OOB = 0x80000000u;
-[[maybe_unused]] constexpr int IDB_RSRC_FLAGS = 0x00020000;
-
-// LDS-staged epilogue (operand-dtype outputs): the accumulator tile goes through LDS so that global traffic is
-// whole 16-byte-per-lane row segments (full 128-B lines) instead of 8-byte pieces at a row stride — measured on the
-// K = C projection GEMMs, the scattered stores alone cost as much as the whole K loop.
-//   phase R (residual only): coalesced copy of the residual tile into LDS
-//   phase W: each lane adds bias / per-sample bias / residual (fp32, ONE rounding) and writes its 4-channel pieces in place
-//   phase S: coalesced LDS -> global stores
-template <typename T, int MF, int NF, bool GEGLU, int WM = 2>
-__device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
-                                                 int wm, int wn, int fr, int fg) {
-    using V8 = typename Op<T>::v8;
-    using V4 = typename Op<T>::v4;
-    constexpr int BM = 16 * MF * WM, BN = 32 * NF, THREADS = 128 * WM;
-    constexpr int BNO = GEGLU ? BN / 2 : BN;          // output columns of this tile
-    constexpr int OLD = BNO * 2 + 16;                  // LDS row stride (bytes), 16-B aligned, de-phased banks
-    constexpr int CPR = BNO / 8;                       // 16-byte chunks per row
-    constexpr int NCHUNK = BM * CPR, ITER = (NCHUNK + THREADS - 1) / THREADS;
-    const int No = GEGLU ? p.N / 2 : p.N;
-    const int n0o = GEGLU ? n0 / 2 : n0;
-    __syncthreads();                                   // every wave is done reading the last K tile
-    if (p.res) {
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int q = it * THREADS + tid;
-            const int row = q / CPR, c = q - row * CPR;
-            const int m = m0 + row, n = n0o + c * 8;
-            if (q < NCHUNK && m < p.M && n < No)
-                *(V8*)(smem + row * OLD + c * 16) = *(const V8*)((const T*)p.res + (long long)m * p.out_ld + n);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int row = (wm * MF + i) * 16 + fr;
-        const int mc = min(m0 + row, p.M - 1);
-        const float* sb = p.sbias ? p.sbias + (long long)(mc / p.HW) * p.sbias_ld : nullptr;
-        if constexpr (GEGLU) {
-#pragma unroll
-            for (int j = 0; j < NF; j += 2) {
-                const int nv = n0 + (wn * NF + j) * 16 + fg * 4;
-                const int col = (wn * NF + j) * 8 + fg * 4;
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][j][e] * p.scale, gt = acc[i][j + 1][e] * p.scale;
-                    if (p.bias && nv + 16 < p.N) {
-                        v += p.bias[nv + e];
-                        gt += p.bias[nv + 16 + e];
-                    }
-                    o[e] = v * gelu_erf_f(gt);
-                }
-                V4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
-                *(V4*)(smem + row * OLD + col * 2) = pk;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int col = (wn * NF + j) * 16 + fg * 4;
-                const int n = n0 + col;
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
-                if (n < p.N) {
-                    if (p.bias) {
-                        const f32x4 b4 = *(const f32x4*)(p.bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += b4[e];
-                    }
-                    if (sb) {
-                        const f32x4 b4 = *(const f32x4*)(sb + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += b4[e];
-                    }
-                }
-                if (p.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(o[e]);
-                }
-                if (p.res) {
-                    const V4 r4 = *(const V4*)(smem + row * OLD + col * 2);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += to_f32<T>(r4[e]);
-                }
-                V4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
-                *(V4*)(smem + row * OLD + col * 2) = pk;
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int q = it * THREADS + tid;
-        const int row = q / CPR, c = q - row * CPR;
-        const int m = m0 + row, n = n0o + c * 8;
-        const int mo = p.dbg_skip_store == 2 ? (m & 127) : m;      // profiling: every tile writes the same L2-resident rows
-        if (q < NCHUNK && m < p.M && n < No) *(V8*)((T*)p.out + (long long)mo * p.out_ld + n) = *(const V8*)(smem + row * OLD + c * 16);
-    }
-}
-
-// Everything after the K loop: LDS-staged coalesced epilogue for operand-dtype outputs, direct epilogue for fp32
-// outputs / split-K slabs / odd widths.
-template <typename T, int MF, int NF, int WM = 2>
-__device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
-                                                  int wm, int wn, int fr, int fg, int kz) {
-    if (p.dbg_skip_store == 1) {            // profiling experiment: keep the accumulators live, write nothing
-        float keep = 0.f;
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (keep == 123.456f) ((float*)p.out)[0] = keep;
-        return;
-    }
-    if (p.splitk > 1) {
-        // ---- split-K: every workgroup stores its fp32 slab (16-B per lane)
-        const bool vec4 = (p.N & 3) == 0;
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int m = m0 + (wm * MF + i) * 16 + fr;
-            if (m >= p.M) continue;
-            float* dst = p.partial + ((long long)kz * p.M + m) * p.N;
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int n = n0 + (wn * NF + j) * 16 + fg * 4;
-                if (p.slab_swc) {
-                    // blocked slab: the reduce + GroupNorm-statistics kernel then reads each of its 64 x swc windows as ONE
-                    // contiguous run (row-major windows of 40-64 channels are 160-256-byte pieces at a row stride)
-                    if (n < p.N) {
-                        const int sl = n / p.slab_swc;
-                        float* blk = p.partial + ((((long long)kz * (p.M >> 6) + (m >> 6)) * (p.N / p.slab_swc) + sl) * 64 + (m & 63)) * p.slab_swc;
-                        *(f32x4*)(blk + (n - sl * p.slab_swc)) = acc[i][j];
-                    }
-                } else if (vec4 && n + 3 < p.N) {
-                    *(f32x4*)(dst + n) = acc[i][j];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.N) dst[n + e] = acc[i][j][e];
-                }
-            }
-        }
-        if (!p.counters) return;                      // two-launch mode: idb_splitk_reduce_kernel finishes the job
-        // ---- publish the slab (agent-scope release), draw a ticket; the last arriver of this tile reduces.
-        // Placement-independent protocol (cdna_hip_programming.md, Guideline 16 / "In-launch split-K reduction").
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        unsigned* flag = (unsigned*)smem;             // the K loop is done with LDS (barrier above)
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned* cnt = p.counters + (m0 / (16 * MF * WM)) * p.tiles_n + n0 / (32 * NF);
-            const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool last = t == (unsigned)p.splitk - 1u;
-            if (last) {
-                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the counter zero for the next launch
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            *flag = last ? 1u : 0u;
-        }
-        __syncthreads();
-        const bool is_last = *flag != 0u;
-        __syncthreads();                              // flag consumed before the epilogue reuses LDS
-        if (!is_last) return;
-        // ---- deterministic reduction: every slab, own one included, in ascending split order (bit-identical to the
-        // two-launch path whoever arrives last)
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int m = m0 + (wm * MF + i) * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int n = n0 + (wn * NF + j) * 16 + fg * 4;
-                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-                if (m < p.M) {
-                    for (int z = 0; z < p.splitk; ++z) {
-                        const float* src = p.partial + ((long long)z * p.M + m) * p.N + n;
-                        if (vec4 && n + 3 < p.N) {
-                            const f32x4 v = *(const f32x4*)src;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) sum[e] += v[e];
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < p.N) sum[e] += src[e];
-                        }
-                    }
-                }
-                acc[i][j] = sum;
-            }
-        }
-    }
-    if (p.lds_epi) {
-        if (p.geglu) {
-            if constexpr ((NF & 1) == 0) idb_lds_epilogue<T, MF, NF, true, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
-        } else {
-            idb_lds_epilogue<T, MF, NF, false, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
-        }
-        return;
-    }
-    // ---- direct epilogue (fp32 outputs, split-K slabs, odd widths): lane holds out[m][n .. n+3], m = tile row (lane&15), n = 4*(lane>>4) + reg
-    const bool vec_ok = (p.N & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int m = m0 + (wm * MF + i) * 16 + fr;
-        if (m >= p.M) continue;
-        const float* sb = p.sbias ? p.sbias + (long long)(m / p.HW) * p.sbias_ld : nullptr;
-        if (p.geglu) {
-            if constexpr ((NF & 1) == 0) {
-#pragma unroll
-                for (int j = 0; j < NF; j += 2) {
-                    const int nv = n0 + (wn * NF + j) * 16 + fg * 4;   // packed row of the value part
-                    if (nv >= p.N) continue;   // N % 32 == 0: a value/gate pair is in range or not as a whole
-                    const int oc = (n0 + (wn * NF + j) * 16) / 2 + fg * 4;
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][e] * p.scale, gt = acc[i][j + 1][e] * p.scale;
-                        if (p.bias) {
-                            v += p.bias[nv + e];
-                            gt += p.bias[nv + 16 + e];
-                        }
-                        o[e] = v * gelu_erf_f(gt);
-                    }
-                    T* dst = (T*)p.out + (long long)m * p.out_ld + oc;
-                    typename Op<T>::v4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
-                    *(typename Op<T>::v4*)dst = pk;
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int n = n0 + (wn * NF + j) * 16 + fg * 4;
-            if (n >= p.N) continue;
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
-            if (vec_ok && n + 3 < p.N) {
-                if (p.bias) {
-                    const f32x4 b4 = *(const f32x4*)(p.bias + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
-                }
-                if (sb) {
-                    const f32x4 b4 = *(const f32x4*)(sb + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
-                }
-                if (p.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(o[e]);
-                }
-                if (p.res) {
-                    const typename Op<T>::v4 r4 = *(const typename Op<T>::v4*)((const T*)p.res + (long long)m * p.out_ld + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += to_f32<T>(r4[e]);
-                }
-                if (p.out_f32) {
-                    *(f32x4*)((float*)p.out + (long long)m * p.out_ld + n) = (f32x4){o[0], o[1], o[2], o[3]};
-                } else {
-                    typename Op<T>::v4 pk = {from_f32<T>(o[0]), from_f32<T>(o[1]), from_f32<T>(o[2]), from_f32<T>(o[3])};
-                    *(typename Op<T>::v4*)((T*)p.out + (long long)m * p.out_ld + n) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (n + e >= p.N) break;
-                    float v = o[e];
-                    if (p.bias) v += p.bias[n + e];
-                    if (sb) v += sb[n + e];
-                    if (p.act == 1) v = gelu_erf_f(v);
-                    if (p.res) v += to_f32<T>(((const T*)p.res)[(long long)m * p.out_ld + n + e]);
-                    if (p.out_f32) ((float*)p.out)[(long long)m * p.out_ld + n + e] = v;
-                    else ((T*)p.out)[(long long)m * p.out_ld + n + e] = from_f32<T>(v);
-                }
-            }
-        }
-    }
-}
+#include "idb_gemm_epi.h"
 
 // __launch_bounds__(256, 2): at most 256 VGPRs so that TWO workgroups share a CU — the second workgroup's MFMAs are what
 // hides this one's LDS-DMA issue, waits and epilogue (one workgroup per CU measured 0.70 vs 1.12 PFLOP/s on the conv shape).
@@ -505,8 +195,8 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * LOADS) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (it + NS - 1 < nk && p.dbg_loop != 2) stage(cur == 0 ? NS - 1 : cur - 1);
-        if (p.dbg_loop == 1) {
+        if (it + NS - 1 < nk && IDB_DBG(p.dbg_loop) != 2) stage(cur == 0 ? NS - 1 : cur - 1);
+        if (IDB_DBG(p.dbg_loop) == 1) {
             cur = cur + 1 == NS ? 0 : cur + 1;
             continue;
         }
@@ -880,154 +570,6 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
 #endif
 }
 
-// Split-K tail: sum the fp32 slabs and apply the same epilogue (bias, per-sample bias, residual).
-// VEC = 4: one thread owns out[m][n .. n+3]; every load of the thread — residual, biases, then the slabs in batches of 8 —
-// is issued unconditionally (clamped slab index, masked in registers) so that the memory round trips overlap: a load inside
-// a data-dependent loop or branch gets an s_waitcnt vmcnt(0) right behind it, and with 8-30 slabs the first version of this
-// kernel spent its time in that many dependent round trips.  Slabs are added in ascending split order (deterministic, and
-// bit-identical to the in-kernel reduce).  VEC = 1 is the scalar fallback for odd widths / unaligned residuals.
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void idb_splitk_reduce_kernel(const float* __restrict__ partial, int splitk,
-                                                                int M, int N, int HW, float scale,
-                                                                const float* bias, const float* sbias, int sbias_ld,
-                                                                const T* res, void* out, int out_ld, int out_f32) {
-    const long long total = (long long)M * N / VEC;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const long long e0 = idx * VEC;
-    const int m = (int)(e0 / N), n = (int)(e0 - (long long)m * N);
-    if constexpr (VEC == 4) {
-        using V4 = typename Op<T>::v4;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        V4 r4;
-        f32x4 bi = zero, sbv = zero;
-        if (res) r4 = *(const V4*)(res + (long long)m * out_ld + n);          // uniform conditions: no divergence, and the
-        if (bias) bi = *(const f32x4*)(bias + n);                                // waits for these sit behind the slab loads
-        if (sbias) sbv = *(const f32x4*)(sbias + (long long)(m / HW) * sbias_ld + n);
-        const float* src = partial + (long long)m * N + n;
-        const long long slab = (long long)M * N;
-        f32x4 v = zero;
-        for (int z0 = 0; z0 < splitk; z0 += 8) {
-            f32x4 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(src + (long long)min(z0 + u, splitk - 1) * slab);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool in = z0 + u < splitk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += in ? t[u][e] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] *= scale;
-            if (bias) v[e] += bi[e];
-            if (sbias) v[e] += sbv[e];
-            if (res) v[e] += to_f32<T>(r4[e]);
-        }
-        if (out_f32) {
-            *(f32x4*)((float*)out + (long long)m * out_ld + n) = v;
-        } else {
-            V4 o = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
-            *(V4*)((T*)out + (long long)m * out_ld + n) = o;
-        }
-    } else {
-        float v = 0.f;
-        for (int z = 0; z < splitk; ++z) v += partial[((long long)z * M + m) * N + n];
-        v *= scale;
-        if (bias) v += bias[n];
-        if (sbias) v += sbias[(long long)(m / HW) * sbias_ld + n];
-        if (res) v += to_f32<T>(res[(long long)m * out_ld + n]);
-        if (out_f32) ((float*)out)[(long long)m * out_ld + n] = v;
-        else ((T*)out)[(long long)m * out_ld + n] = from_f32<T>(v);
-    }
-}
-
-// Split-K tail that also emits the first GroupNorm pass of its output (idb_gemm_desc.gn_partials): one workgroup owns 64
-// rows x SWC channels (SWC a multiple of the group width and of 4, SWC <= 64) with ONE thread per (row, 4 channels), so that —
-// as in idb_splitk_reduce_kernel<T,4> — every load of a thread is in flight at once.  It sums the slabs, applies the
-// epilogue, stores the rounded result, and reduces {x, x^2} of the ROUNDED values per group through LDS (fixed order:
-// deterministic).  Saves the statistics launch of the GroupNorm that follows a split-K convolution: 9.2 us against
-// 5.5 + 5.4 us (batch 1: +0.7 %).  Measured and dropped: a serial 6-rows-per-thread form (slower than the two launches) and a
-// 2-rows-per-thread form with 80-128-channel slices (longer contiguous runs but half the workgroups: no gain).
-template <typename T>
-__global__ __launch_bounds__(1024) void idb_splitk_reduce_gn_kernel(const float* __restrict__ partial, int splitk, int M, int N,
-                                                                    int HW, float scale, const float* bias, const float* sbias,
-                                                                    int sbias_ld, const T* res, T* out, int out_ld, float* gn_part,
-                                                                    int groups, int swc) {
-    using V4 = typename Op<T>::v4;
-    __shared__ float part[1024][2][2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cols = swc >> 2;                                  // blockDim.x == 64 * cols
-    const int col = tid % cols, row = tid / cols;
-    const int cpg = N / groups;
-    const int n = blockIdx.y * swc + col * 4;
-    const int m_blk = blockIdx.x * 64, m = m_blk + row;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    V4 r4;
-    f32x4 bi = zero, sbv = zero;
-    if (res) r4 = *(const V4*)(res + (long long)m * out_ld + n);
-    if (bias) bi = *(const f32x4*)(bias + n);
-    if (sbias) sbv = *(const f32x4*)(sbias + (long long)(m / HW) * sbias_ld + n);
-    // slabs in the blocked layout GemmParams::slab_swc describes: this workgroup's window is one contiguous run per slab
-    const float* src = partial + (((long long)blockIdx.x * gridDim.y + blockIdx.y) * 64 + row) * swc + col * 4;
-    const long long slab = (long long)M * N;
-    f32x4 v = zero;
-    for (int z0 = 0; z0 < splitk; z0 += 8) {
-        f32x4 t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(src + (long long)min(z0 + u, splitk - 1) * slab);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool in = z0 + u < splitk;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += in ? t[u][e] : 0.f;
-        }
-    }
-    const int g_first = n / cpg;
-    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
-    V4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float x = v[e] * scale;
-        if (bias) x += bi[e];
-        if (sbias) x += sbv[e];
-        if (res) x += to_f32<T>(r4[e]);
-        o[e] = from_f32<T>(x);
-        const float xr = to_f32<T>(o[e]);
-        const int k = ((n + e) / cpg - g_first) & 1;            // four channels touch at most two groups (cpg >= 2)
-        gs[k] += xr;
-        gq[k] += xr * xr;
-    }
-    *(V4*)(out + (long long)m * out_ld + n) = o;
-    part[tid][0][0] = gs[0]; part[tid][0][1] = gq[0];
-    part[tid][1][0] = gs[1]; part[tid][1][1] = gq[1];
-    __syncthreads();
-    const int gps = swc / cpg, nact = cols * 64, nwaves = cols;   // 64 * cols threads = cols waves
-    const int slice_g0 = blockIdx.y * gps;
-    const int nch = HW >> 6;
-    const int b = m_blk / HW, chunk = (m_blk - b * HW) >> 6;
-    for (int gl = wave; gl < gps; gl += nwaves) {
-        const int ga = slice_g0 + gl;
-        float a = 0.f, q = 0.f;
-        for (int t = lane; t < nact; t += 64) {
-            const int tc = blockIdx.y * swc + (t % cols) * 4;
-            const int k = ga - tc / cpg;
-            if (k == 0 || k == 1) {
-                a += part[t][k][0];
-                q += part[t][k][1];
-            }
-        }
-        a = wave_sum(a);
-        q = wave_sum(q);
-        if (lane == 0) {
-            float* dst = gn_part + (((long long)b * nch + chunk) * groups + ga) * 2;
-            dst[0] = a;
-            dst[1] = q;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1276,18 +818,6 @@ int launch_tile_pl(const GemmParams& p, const Plan& pl, hipStream_t st) {
     return IDB_OK;
 }
 
-// slice width of idb_splitk_reduce_gn_kernel: the largest multiple of lcm(group width, 4) that is <= 64 and divides n (one thread
-// per row and 4 channels: 64 * swc / 4 <= 1024 threads); 0 if there is none
-inline int gn_reduce_slice(int n, int groups) {
-    const int cpg = n / groups;
-    int base = cpg;
-    while (base % 4) base += cpg;
-    int swc = 0;
-    for (int c = base; c <= 64; c += base)
-        if (n % c == 0) swc = c;
-    return swc;
-}
-
 template <typename T>
 int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
     int rc;
@@ -1319,35 +849,8 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         case 23: rc = launch_tile<T, 2, 5, 4>(p, pl, st); break;
         default: rc = launch_tile<T, 4, 1, 2>(p, pl, st); break;
     }
-    if (rc == IDB_OK && d->gn_partials && (pl.splitk == 1 || p.counters) && !(d->flags & 1))
-        return idb_launch_gn_stats64(p.out, d->n, d->batch, p.HW, d->gn_groups, d->gn_partials, d->dtype, st);   // no reduce launch to ride on
-    if (rc != IDB_OK || pl.splitk == 1 || (d->flags & 1) || p.counters) return rc;
-    const bool vec_ok = d->n % 4 == 0 && d->out_ld % 4 == 0 && idb_aligned16(p.partial) && (!p.bias || idb_aligned16(p.bias)) &&
-                        (!p.sbias || (idb_aligned16(p.sbias) && p.sbias_ld % 4 == 0)) && (!p.res || ((uintptr_t)p.res & 7) == 0) &&
-                        ((uintptr_t)p.out & 15) == 0;
-    if (p.slab_swc) {
-        {
-            const int swc = p.slab_swc;       // chosen in idb_gemm together with the blocked slab layout the GEMM has just written
-            hipLaunchKernelGGL((idb_splitk_reduce_gn_kernel<T>), dim3(pl.M / 64, d->n / swc), dim3(16 * swc), 0, st, p.partial, pl.splitk,
-                               pl.M, d->n, p.HW, p.scale, p.bias, p.sbias, p.sbias_ld, (const T*)p.res, (T*)p.out, p.out_ld,
-                               d->gn_partials, d->gn_groups, swc);
-            IDB_CHECK_LAUNCH("idb_splitk_reduce_gn");
-            return IDB_OK;
-        }
-    }
-    const int vec = vec_ok ? 4 : 1;
-    const long long total = (long long)pl.M * d->n / vec;
-    const int blocks = (int)((total + 255) / 256);
-    if (vec == 4)
-        hipLaunchKernelGGL((idb_splitk_reduce_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, p.partial, pl.splitk, pl.M,
-                           d->n, p.HW, p.scale, p.bias, p.sbias, p.sbias_ld, (const T*)p.res, p.out, p.out_ld, p.out_f32);
-    else
-        hipLaunchKernelGGL((idb_splitk_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, p.partial, pl.splitk, pl.M,
-                           d->n, p.HW, p.scale, p.bias, p.sbias, p.sbias_ld, (const T*)p.res, p.out, p.out_ld, p.out_f32);
-    IDB_CHECK_LAUNCH("idb_splitk_reduce");
-    if (d->gn_partials)
-        return idb_launch_gn_stats64(p.out, d->n, d->batch, p.HW, d->gn_groups, d->gn_partials, d->dtype, st);
-    return IDB_OK;
+    if (rc != IDB_OK || (d->flags & 1)) return rc;
+    return idb_finish_splitk<T>(p, pl.M, d->n, d->batch, pl.splitk, d->gn_partials, d->gn_groups, d->dtype, st);
 }
 
 }  // namespace
@@ -1414,6 +917,9 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     p.partial = (float*)workspace;
     p.tiles_n = pl.tiles_n;
+#ifndef IDB_PROFILING
+    IDB_REQUIRE(!(d->flags & (2 | 32 | 64 | 128)), "idb_gemm: flags bits 1/5/6/7 are profiling switches of libidb_kernels_prof.so (make prof)");
+#endif
     p.dbg_skip_store = (d->flags & 2) ? 1 : ((d->flags & 32) ? 2 : 0);
     p.out_bytes = (unsigned)((long long)pl.M * d->out_ld * 2);
     p.act = d->act;
@@ -1435,10 +941,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.slab_swc = 0;
     if (d->gn_partials && pl.splitk > 1 && !p.counters && !(d->flags & 1) && !p.out_f32 && pl.M % 64 == 0) {
         // the reduce launch will be idb_splitk_reduce_gn_kernel: same conditions and slice width as launch_all computes
-        const bool vec_ok = d->n % 4 == 0 && d->out_ld % 4 == 0 && idb_aligned16(p.partial) && (!p.bias || idb_aligned16(p.bias)) &&
-                            (!p.sbias || (idb_aligned16(p.sbias) && p.sbias_ld % 4 == 0)) && (!p.res || ((uintptr_t)p.res & 7) == 0) &&
-                            ((uintptr_t)p.out & 15) == 0;
-        if (vec_ok) p.slab_swc = gn_reduce_slice(d->n, d->gn_groups);
+        if (idb_reduce_vec_ok(p, d->n)) p.slab_swc = gn_reduce_slice(d->n, d->gn_groups);
     }
     hipStream_t st = (hipStream_t)stream;
     return d->dtype == IDB_BF16 ? launch_all<__bf16>(d, p, pl, st) : launch_all<_Float16>(d, p, pl, st);

@@ -1,0 +1,633 @@
+// K1 — "GroupNorm(+SiLU) -> conv3x3 / 1x1" of diffusers ResnetBlock2D (norm1+conv1, norm2+conv2+conv_shortcut) and
+// Transformer2DModel (norm + proj_in) as ONE kernel: the normalisation is applied to the conv's input tile inside LDS, so the
+// normalised tensor never exists in HBM and the separate gn_apply launch disappears (reached from
+// /root/reference/inference_ID-Booth.py:138 through UNet2DConditionModel.forward).
+//
+// Design (MI355X), differences from idb_gemm_kernel (idb_gemm.hip):
+//   * K order is [64-channel chunk][tap] instead of [tap][chunk]: the input PATCH of a chunk — the tile's 128 output pixels
+//     plus their 3x3 halo, one 128-byte row per pixel — is staged into LDS ONCE per chunk (LDS-DMA, zero fill for the
+//     padding) and the 9 taps read shifted windows of it.  An im2col K loop moves the tile's rows 9 times: 147 KB per chunk
+//     against 23-34 KB here, and issues 45 LDS-DMA instructions per wave and chunk against 30.
+//   * Once per chunk the landed patch is normalised in place: y = silu(x * scale[b][c] + shift[b][c]), scale/shift built in the
+//     prologue from the producer's partial statistics (idb_gemm_desc.gn_partials / idb_groupnorm_stats) — each patch element
+//     is transformed once per chunk, not once per tap and fragment; padding rows stay zero (the mask comes after the activation).
+//   * tiles are 128 CONSECUTIVE output rows (whole image rows of maps up to 64 wide, or several whole samples of maps smaller
+//     than 128 pixels), so the epilogues, split-K slabs and reduce launches of idb_gemm_epi.h are used unchanged.
+//   * weights stream through a 3-stage LDS ring exactly as in idb_gemm_kernel; the patch is double-buffered; every LDS-DMA is
+//     counted in software per wave (issue order), the wait before a K-step is the largest supported vmcnt immediate that still
+//     covers what the step reads; one barrier per K-step.
+// Regime: one workgroup per CU (152 KB of LDS), i.e. the small-batch sampler; the engine keeps idb_groupnorm + idb_gemm for
+// shapes this kernel does not take (idb_hconv_plan says which).
+#include "idb_gemm_epi.h"
+
+namespace {
+
+constexpr int HC_NPP = 5;                      // patch LDS-DMA instructions per wave and chunk (8 rows each, 8 waves): 320 rows
+constexpr int HC_PROWS = HC_NPP * 64;
+constexpr int HC_PBYTES = HC_PROWS * 128;
+constexpr int HC_NS = 3;                       // weight ring stages
+constexpr int HC_TBL_BYTES = 6144, HC_TBL_CAP = HC_TBL_BYTES / 8;     // {scale, shift} entries
+constexpr int HC_GSTAT_BYTES = 2048;           // {mean, rstd} of up to 256 (sample, group) pairs
+
+struct HcSeg {
+    const char* x0;
+    const char* x1;
+    unsigned bytes0, bytes1;
+    int C0, C1, taps, kbase, nchunks;          // kbase: K offset (elements) of the segment in a weight row
+};
+
+struct HcParams {
+    GemmParams g;                              // epilogue / split-K fields; g.src is unused
+    HcSeg seg[2];
+    int nseg, H, W, TPX, NB, TH, PW, PS, P;
+    // fused GroupNorm of segment 0 (gn_partials == nullptr: none)
+    const float* gn_partials;
+    const float* gamma;
+    const float* beta;
+    int gn_chunks, groups, cpg, silu;
+    float eps;
+};
+
+// K-step cursor (segment, chunk, tap), order [segment][chunk][tap].  Free functions with explicit arguments: capturing lambdas
+// that call each other, or that capture variables an asm statement modifies, defeat SROA here and put every local into scratch.
+__device__ __forceinline__ void hc_advance(int& s, int& c, int& t, int taps0, int taps1, int nch0, int nch1) {
+    if (++t == (s == 0 ? taps0 : taps1)) {
+        t = 0;
+        if (++c == (s == 0 ? nch0 : nch1)) {
+            c = 0;
+            ++s;                                                     // may run past the last segment at the very end: never used then
+        }
+    }
+}
+
+// in-place normalisation of one 16-byte chunk of a landed patch: y = [silu](x * scale + shift)
+template <typename T>
+__device__ __forceinline__ void hc_norm16(char* a, const float2* e, int silu) {
+    using V8 = typename Op<T>::v8;
+    const V8 raw = *(const V8*)a;
+    V8 o;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        float y = to_f32<T>(raw[u]) * e[u].x + e[u].y;
+        if (silu) y = silu_f(y);
+        o[u] = from_f32<T>(y);
+    }
+    *(V8*)a = o;
+}
+
+template <typename T, int NF>
+__global__ __launch_bounds__(512, 2) void idb_hconv_kernel(const HcParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using V8 = typename Op<T>::v8;
+    constexpr int MF = 2, WM = 4, BM = 128, BN = 32 * NF, RS = 64;
+    constexpr int NJ = (BN + RS - 1) / RS, WSTAGE = NJ * RS * 128;
+    constexpr int LW = NJ;                                           // weight DMA instructions per wave and K-step
+    constexpr int OFF_W = 2 * HC_PBYTES, OFF_TBL = OFF_W + HC_NS * WSTAGE, OFF_GST = OFF_TBL + HC_TBL_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // ---- tile / K-slice (same XCD-aware remaps as idb_gemm_kernel)
+    int wg, kz;
+    if (p.g.xcd_mode == 0) {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        kz = blockIdx.z;
+    } else {
+        const int X = gridDim.x;
+        const int lin = blockIdx.x + X * blockIdx.z;
+        const int xcd = lin & 7, j = lin >> 3;
+        if (p.g.xcd_mode == 1) {
+            kz = xcd + 8 * (j / X);
+            wg = j % X;
+        } else {
+            kz = xcd >> 1;
+            wg = (xcd & 1) * (X >> 1) + j;
+        }
+    }
+    const int tm = wg / p.g.tiles_n, tn = wg - tm * p.g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt0 = (int)(((long long)kz * p.g.ktiles) / p.g.splitk);
+    const int kt1 = (int)(((long long)(kz + 1) * p.g.ktiles) / p.g.splitk);
+    const int nk = kt1 - kt0;
+
+    const int b0 = m0 / p.g.HW;                                      // first sample of the tile
+    const int y0 = p.NB == 1 ? (m0 - b0 * p.g.HW) / p.W : 0;          // first image row of the tile (whole samples: 0)
+
+    // ---- staging coordinates: wave-instruction `it` of this wave fills patch rows (it*8 + wave)*8 .. +7, lane = (row, chunk position)
+    const int srow = lane >> 3;
+    const unsigned cg16 = (unsigned)(((lane & 7) ^ srow) * 16);      // 16-byte chunk fetched: position ^ (row & 7), swizzle on the source
+    int pixh[HC_NPP], pixc[2];                                       // source pixel (linear index) per staged row; -1: padding / beyond the patch
+#pragma unroll
+    for (int it = 0; it < HC_NPP; ++it) {
+        const int pr = (it * 8 + wave) * 8 + srow;
+        const int nb = pr / p.PS, rem = pr - nb * p.PS;
+        const int py = rem / p.PW, px = rem - py * p.PW;
+        const int y = y0 + py - 1, x = px - 1;
+        const bool ok = pr < p.P && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        pixh[it] = ok ? ((b0 + nb) * p.H + y) * p.W + x : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) pixc[it] = m0 + (it * 8 + wave) * 8 + srow;      // 1x1 segments: the 128 tile rows themselves
+
+    // ---- transform items: thread handles 16-byte chunks idx = j*512 + tid of the patch (row idx >> 3, position idx & 7)
+    const int tcap = HC_TBL_CAP / p.NB;                              // table entries per sample
+    int t_tbl[HC_NPP];                                               // table offset of the item's first channel (without the chunk base); -1: skip
+#pragma unroll
+    for (int j = 0; j < HC_NPP; ++j) {
+        const int idx = j * 512 + tid, pr = idx >> 3, cp = idx & 7;
+        const int nb = pr / p.PS, rem = pr - nb * p.PS;
+        const int py = rem / p.PW, px = rem - py * p.PW;
+        const int y = y0 + py - 1, x = px - 1;
+        const bool ok = pr < p.P && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        t_tbl[j] = ok ? nb * tcap + ((cp ^ (pr & 7)) * 8) : -1;
+    }
+    // compact (1x1) patches: items j = 0, 1 are rows (j*512 + tid) >> 3
+    const int tc_ch = (((tid & 7) ^ ((tid >> 3) & 7)) * 8);
+    const int tc_off0 = ((tid >> 3) / p.TPX) * tcap + tc_ch, tc_off1 = (((512 + tid) >> 3) / p.TPX) * tcap + tc_ch;
+
+    // ---- fragment rows of this wave: tile row r -> patch row of tap (0,0)
+    int pbase[MF], cbase[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int r = (wm * MF + i) * 16 + fr;
+        const int nb = r / p.TPX, rr = r - nb * p.TPX;
+        const int ty = rr / p.W, tx = rr - ty * p.W;
+        pbase[i] = (nb * (p.TH + 2) + ty) * p.PW + tx;
+        cbase[i] = r;
+    }
+
+    // ---- weights: per-row voffset fixed, K position in the soffset
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.g.w, 0, p.g.w_bytes, IDB_RSRC_FLAGS);
+    const int lrow = tid >> 3;
+    unsigned w_voff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + j * RS + lrow;
+        w_voff[j] = (n < p.g.N && j * RS + lrow < BN) ? (unsigned)n * p.g.w_row_bytes + cg16 : IDB_OOB;
+    }
+
+    // ---- segment fields as opaque scalars: a select between two kernel-argument LOADS becomes a dynamically indexed load of the
+    // by-value argument struct, which the compiler serves by copying the struct to scratch
+#define HC_OPAQUE(type, name, expr) type name = (expr); asm volatile("" : "+s"(name))
+    HC_OPAQUE(int, taps0, p.seg[0].taps); HC_OPAQUE(int, taps1, p.seg[1].taps);
+    HC_OPAQUE(int, nch0, p.seg[0].nchunks); HC_OPAQUE(int, nch1, p.seg[1].nchunks);
+    HC_OPAQUE(int, kb0, p.seg[0].kbase); HC_OPAQUE(int, kb1, p.seg[1].kbase);
+    HC_OPAQUE(int, c00, p.seg[0].C0); HC_OPAQUE(int, c01, p.seg[0].C1);
+    HC_OPAQUE(int, c10, p.seg[1].C0); HC_OPAQUE(int, c11, p.seg[1].C1);
+    HC_OPAQUE(const char*, x00, p.seg[0].x0); HC_OPAQUE(const char*, x01, p.seg[0].x1);
+    HC_OPAQUE(const char*, x10, p.seg[1].x0); HC_OPAQUE(const char*, x11, p.seg[1].x1);
+    HC_OPAQUE(unsigned, nb00, p.seg[0].bytes0); HC_OPAQUE(unsigned, nb01, p.seg[0].bytes1);
+    HC_OPAQUE(unsigned, nb10, p.seg[1].bytes0); HC_OPAQUE(unsigned, nb11, p.seg[1].bytes1);
+#undef HC_OPAQUE
+    const int ct0 = c00 + c01, ct1 = c10 + c11;
+#define HC_TAPS(s_) ((s_) == 0 ? taps0 : taps1)
+
+    // ---- cursors: compute (cs, cch, ctp) and weight load (ls, lch, ltp; HC_NS - 1 steps ahead)
+    int cs = 0, cch, ctp;
+    {
+        int rem = kt0;
+        if (p.nseg > 1 && rem >= nch0 * taps0) {
+            rem -= nch0 * taps0;
+            cs = 1;
+        }
+        const int tp = HC_TAPS(cs);
+        cch = rem / tp;
+        ctp = rem - cch * tp;
+    }
+    int ls = cs, lch = cch, ltp = ctp;
+    const int first_chunk0 = cch;                                    // segment-0 chunk range of this workgroup: table base
+    const bool has_gn = p.gn_partials != nullptr;
+
+    // ---- software accounting of this wave's LDS-DMA instructions (in issue order; vmcnt counts them in the same order);
+    // named scalars, not arrays: a run-time index would put an array into scratch memory
+    int issued = 0;
+    int w_end0 = 0, w_end1 = 0, w_end2 = 0, p_end0 = 0, p_end1 = 0;
+
+#define HC_STAGE_W(buf_)                                                                                                           \
+    do {                                                                                                                           \
+        const int bw_ = (buf_);                                                                                                    \
+        const unsigned soff_ = (unsigned)((ls == 0 ? kb0 : kb1) + ltp * (ls == 0 ? ct0 : ct1) + lch * 64) * 2u;                    \
+        char* sB_ = smem + OFF_W + bw_ * WSTAGE;                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB_ + (j * 512 + wave * 64) * 16), 16, w_voff[j], soff_, 0, 0); \
+        issued += LW;                                                                                                              \
+        if (bw_ == 0) w_end0 = issued;                                                                                             \
+        else if (bw_ == 1) w_end1 = issued;                                                                                        \
+        else w_end2 = issued;                                                                                                      \
+        hc_advance(ls, lch, ltp, taps0, taps1, nch0, nch1);                                                                        \
+    } while (0)
+
+#define HC_STAGE_PATCH(buf_, s_, c_)                                                                                               \
+    do {                                                                                                                           \
+        const int bp_ = (buf_), sp_ = (s_), ch_ = (c_) * 64;                                                                       \
+        const int sC0_ = sp_ == 0 ? c00 : c10;                                                                                     \
+        const bool second_ = ch_ >= sC0_;                                                                                          \
+        const char* base_ = sp_ == 0 ? (second_ ? x01 : x00) : (second_ ? x11 : x10);                                              \
+        const int C_ = second_ ? (sp_ == 0 ? c01 : c11) : sC0_;                                                                    \
+        const unsigned nbytes_ = sp_ == 0 ? (second_ ? nb01 : nb00) : (second_ ? nb11 : nb10);                                     \
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)base_, 0, nbytes_, IDB_RSRC_FLAGS);           \
+        const unsigned soffp_ = (unsigned)(ch_ - (second_ ? sC0_ : 0)) * 2u;                                                       \
+        char* sP_ = smem + bp_ * HC_PBYTES;                                                                                        \
+        if (HC_TAPS(sp_) == 9) {                                                                                                   \
+            _Pragma("unroll") for (int it = 0; it < HC_NPP; ++it) {                                                                \
+                const unsigned voff_ = pixh[it] >= 0 ? (unsigned)pixh[it] * (unsigned)(C_ * 2) + cg16 : IDB_OOB;                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, LDS_PTR(sP_ + ((it * 8 + wave) * 64) * 16), 16, voff_, soffp_, 0, 0); \
+            }                                                                                                                      \
+            issued += HC_NPP;                                                                                                      \
+        } else {                                                                                                                   \
+            _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                                     \
+                const unsigned voff_ = (unsigned)pixc[it] * (unsigned)(C_ * 2) + cg16;                                             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, LDS_PTR(sP_ + ((it * 8 + wave) * 64) * 16), 16, voff_, soffp_, 0, 0); \
+            }                                                                                                                      \
+            issued += 2;                                                                                                           \
+        }                                                                                                                          \
+        if (bp_ == 0) p_end0 = issued;                                                                                             \
+        else p_end1 = issued;                                                                                                      \
+    } while (0)
+
+    // in-place normalisation of a landed patch on the real pixels; padding rows stay zero
+    const float2* tbl = (const float2*)(smem + OFF_TBL);
+#define HC_TRANSFORM(buf_, c_, compact_)                                                                                           \
+    do {                                                                                                                           \
+        char* sT_ = smem + (buf_) * HC_PBYTES;                                                                                     \
+        const int crel_ = ((c_) - first_chunk0) * 64;                                                                              \
+        if (!(compact_)) {                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < HC_NPP; ++j)                                                                     \
+                if (t_tbl[j] >= 0) hc_norm16<T>(sT_ + (j * 512 + tid) * 16, tbl + t_tbl[j] + crel_, p.silu);                       \
+        } else {                                                                                                                   \
+            hc_norm16<T>(sT_ + tid * 16, tbl + tc_off0 + crel_, p.silu);                                                           \
+            hc_norm16<T>(sT_ + (512 + tid) * 16, tbl + tc_off1 + crel_, p.silu);                                                   \
+        }                                                                                                                          \
+    } while (0)
+
+    // ---- prologue: first patch, first weight tiles, then (with ordinary loads, while those are in flight) the scale/shift table
+    int cbuf = 0;                                                    // patch buffer of the compute cursor's chunk
+    HC_STAGE_PATCH(0, cs, cch);
+#pragma unroll
+    for (int st = 0; st < HC_NS - 1; ++st)
+        if (st < nk) HC_STAGE_W(st);
+
+    if (has_gn && cs == 0) {
+        // this workgroup's segment-0 channel range: chunks [first_chunk0, last_chunk0]
+        float2* tblw = (float2*)(smem + OFF_TBL);
+        const int steps0 = nch0 * taps0;
+        const int last_kt = (kt1 < steps0 ? kt1 : steps0) - 1;
+        const int last_chunk0 = last_kt / taps0;
+        const int ca = first_chunk0 * 64, ncr = (last_chunk0 - first_chunk0 + 1) * 64;
+        const int g_lo = ca / p.cpg, g_hi = (ca + ncr - 1) / p.cpg, ng = g_hi - g_lo + 1;
+        float2* gst = (float2*)(smem + OFF_GST);
+        const int sub = tid & 7;
+        for (int pair = tid >> 3; pair < p.NB * ng; pair += 64) {
+            const int nb = pair / ng, g = g_lo + (pair - nb * ng);
+            float a = 0.f, q = 0.f;
+            for (int k = sub; k < p.gn_chunks; k += 8) {
+                const f32x2 v = *(const f32x2*)(p.gn_partials + (((long long)(b0 + nb) * p.gn_chunks + k) * p.groups + g) * 2);
+                a += v[0];
+                q += v[1];
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if (sub == 0) {
+                const double cnt = (double)p.g.HW * p.cpg;
+                const double mean = (double)a / cnt;
+                double var = (double)q / cnt - mean * mean;
+                if (var < 0.0) var = 0.0;
+                gst[pair] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.eps)));
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < p.NB * ncr; e += 512) {
+            const int nb = e / ncr, cl = e - nb * ncr, c = ca + cl;
+            const float2 mr = gst[nb * ng + (c / p.cpg - g_lo)];
+            const float k = mr.y * p.gamma[c];
+            tblw[nb * tcap + cl] = make_float2(k, p.beta[c] - mr.x * k);
+        }
+        // visibility of the table: the barrier at the top of the first K-step
+    }
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- K loop.  Patch states: cur_tr / nxt_tr = the (current / next) patch has been normalised (or needs no normalisation);
+    // nxt_issue = K-step at which the next chunk's patch was issued.
+    bool cur_tr = !(has_gn && cs == 0);
+    bool nxt_tr = true, nxt_valid = false;
+    int nxt_issue = -1, nxt_s = 0, nxt_c = 0;
+    int cur = 0;                                                     // weight ring stage of step `it`
+    bool first_of_chunk = true;                                      // the step is the first one (of this workgroup) on its chunk
+    for (int it = 0; it < nk; ++it) {
+        const int taps = HC_TAPS(cs);
+        const bool last_of_chunk = ctp == taps - 1 || it == nk - 1;
+        // does this step normalise the next patch?  (landed everywhere after this step's barrier if every wave waits for it now)
+        const bool tr_next_now = nxt_valid && !nxt_tr && (it >= nxt_issue + 3 || last_of_chunk);
+        int need = cur == 0 ? w_end0 : (cur == 1 ? w_end1 : w_end2);
+        const int pe_cur = cbuf == 0 ? p_end0 : p_end1, pe_nxt = cbuf == 0 ? p_end1 : p_end0;
+        if (first_of_chunk && pe_cur > need) need = pe_cur;
+        if (tr_next_now && pe_nxt > need) need = pe_nxt;
+        const int allowed = issued - need;
+        if (allowed >= LW + HC_NPP)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LW + HC_NPP) : "memory");
+        else if (allowed >= LW)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+        // issue: weights of step it + 2; at a chunk's first step the NEXT chunk's patch (into the buffer the previous chunk has
+        // just left: every wave is past that chunk's last read, the barrier above proves it)
+        const bool more_w = it + HC_NS - 1 < nk;
+        bool patch_now = false;
+        int ns = cs, nc = cch, nt = taps - 1;
+        if (first_of_chunk && !nxt_valid && it + (taps - ctp) < nk) {  // next chunk inside this workgroup's K range
+            hc_advance(ns, nc, nt, taps0, taps1, nch0, nch1);
+            patch_now = true;
+        }
+        const int wbuf = cur == 0 ? HC_NS - 1 : cur - 1;
+        if (taps == 1) {                                             // 1x1 chunks last one step: patch first, it is needed next step
+            if (patch_now) HC_STAGE_PATCH(cbuf ^ 1, ns, nc);
+            if (more_w) HC_STAGE_W(wbuf);
+        } else {
+            if (more_w) HC_STAGE_W(wbuf);
+            if (patch_now) HC_STAGE_PATCH(cbuf ^ 1, ns, nc);
+        }
+        if (patch_now) {
+            nxt_valid = true;
+            nxt_issue = it;
+            nxt_s = ns;
+            nxt_c = nc;
+            nxt_tr = !(has_gn && ns == 0);
+        }
+
+        if (!cur_tr) {                                               // not normalised ahead of time (first chunk, 1x1 chunks): now, then a barrier
+            HC_TRANSFORM(cbuf, cch, taps == 1);
+            cur_tr = true;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (tr_next_now) {
+            HC_TRANSFORM(cbuf ^ 1, nxt_c, HC_TAPS(nxt_s) == 1);
+            nxt_tr = true;
+        }
+
+        // MFMAs of this step: weight fragment = A operand, activation fragment = B operand (idb_gemm_kernel's convention)
+        const char* sP = smem + cbuf * HC_PBYTES;
+        const char* sB = smem + OFF_W + cur * WSTAGE + (wn * 16 * NF + fr) * 128;
+        const int t3 = ctp / 3;
+        const int tapoff = taps == 9 ? t3 * p.PW + (ctp - t3 * 3) : 0;
+        int prow[MF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) prow[i] = taps == 9 ? pbase[i] + tapoff : cbase[i];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            V8 af[MF], wf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const V8*)(sP + prow[i] * 128 + (((ks * 4 + fg) ^ (prow[i] & 7)) * 16));
+            const int pos = ((ks * 4 + fg) ^ (fr & 7)) * 16;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *(const V8*)(sB + j * 16 * 128 + pos);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
+        }
+
+        // advance
+        cur = cur + 1 == HC_NS ? 0 : cur + 1;
+        const int os = cs, oc = cch;
+        hc_advance(cs, cch, ctp, taps0, taps1, nch0, nch1);
+        first_of_chunk = cs != os || cch != oc;
+        if (first_of_chunk) {
+            cbuf ^= 1;
+            cur_tr = nxt_tr;
+            nxt_valid = false;
+            nxt_tr = true;
+        }
+    }
+#undef HC_STAGE_W
+#undef HC_STAGE_PATCH
+#undef HC_TRANSFORM
+#undef HC_TAPS
+
+    idb_gemm_epilogue<T, MF, NF, WM>(p.g, smem, acc, m0, n0, tid, wm, wn, fr, fg, kz);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct HcPlan {
+    int M, nf, tiles_m, tiles_n, ktiles, splitk, NB, TPX, TH, PW, PS, P;
+    long long K;
+};
+
+int plan_hconv(const idb_hconv_desc* d, HcPlan* pl) {
+    IDB_REQUIRE(d != nullptr, "idb_hconv: null descriptor");
+    IDB_REQUIRE(idb_is_operand_dtype(d->dtype), "idb_hconv: dtype must be bf16 or f16");
+    IDB_REQUIRE(d->batch > 0 && d->h > 0 && d->w > 0 && d->n > 0, "idb_hconv: non-positive dims");
+    IDB_REQUIRE(d->nseg >= 1 && d->nseg <= 2, "idb_hconv: nseg must be 1 or 2");
+    IDB_REQUIRE(d->w_ptr && idb_aligned16(d->w_ptr) && d->out && idb_aligned16(d->out), "idb_hconv: w/out null or unaligned");
+    IDB_REQUIRE(d->out_ld >= d->n && d->out_ld % 8 == 0 && d->n % 8 == 0, "idb_hconv: n and out_ld must be multiples of 8, out_ld >= n");
+    const long long hw = (long long)d->h * d->w, M = (long long)d->batch * hw;
+    IDB_REQUIRE(M < (1LL << 31) && M % 128 == 0, "idb_hconv: batch*h*w must be a multiple of 128");
+    long long K = 0;
+    int ktiles = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const idb_hconv_seg& S = d->seg[s];
+        IDB_REQUIRE(S.x0 && idb_aligned16(S.x0) && S.c0 > 0 && S.c0 % 64 == 0, "idb_hconv: seg[%d].x0/c0 invalid", s);
+        IDB_REQUIRE((S.x1 == nullptr) == (S.c1 == 0) && S.c1 % 64 == 0 && (!S.x1 || idb_aligned16(S.x1)), "idb_hconv: seg[%d].x1/c1 invalid", s);
+        IDB_REQUIRE(S.taps == 9 || S.taps == 1, "idb_hconv: seg[%d].taps must be 9 or 1", s);
+        IDB_REQUIRE(M * (long long)(S.c0 > S.c1 ? S.c0 : S.c1) * 2 < (1LL << 31), "idb_hconv: seg[%d] tensor is >= 2 GiB; split the batch", s);
+        K += (long long)S.taps * (S.c0 + S.c1);
+        ktiles += S.taps * ((S.c0 + S.c1) / 64);
+    }
+    IDB_REQUIRE((long long)d->n * K * 2 < (1LL << 31), "idb_hconv: weight matrix is >= 2 GiB");
+    if (d->gn_partials) {
+        const int C = d->seg[0].c0 + d->seg[0].c1;
+        IDB_REQUIRE(d->gn_groups > 0 && C % d->gn_groups == 0 && d->gn_chunks > 0 && d->gamma && d->beta && idb_aligned16(d->gn_partials),
+                    "idb_hconv: fused GroupNorm needs groups | C, chunks > 0, gamma, beta, 16-byte aligned partials");
+    }
+    if (d->gn_partials_out) {
+        IDB_REQUIRE(d->gn_groups_out > 0 && d->n % d->gn_groups_out == 0 && d->n / d->gn_groups_out >= 2 && hw % 64 == 0 && hw <= 4096 &&
+                        d->out_ld == d->n && idb_aligned16(d->gn_partials_out),
+                    "idb_hconv: gn_partials_out needs n %% groups == 0, dense output, h*w %% 64 == 0 and <= 4096");
+    }
+    // geometry: a tile is 128 consecutive output rows = whole image rows (w <= 64, 128 % w == 0) or whole samples (h*w < 128)
+    int NB = 1, TPX = 128;
+    if (hw < 128) {
+        if (128 % hw) { idb_set_error("idb_hconv: h*w=%lld does not divide 128", hw); return IDB_EUNSUPPORTED; }
+        NB = (int)(128 / hw);
+        TPX = (int)hw;
+        if (d->batch % NB) { idb_set_error("idb_hconv: batch must be a multiple of %d for %dx%d maps", NB, d->h, d->w); return IDB_EUNSUPPORTED; }
+    } else if (hw % 128 || d->w > 64 || 128 % d->w) {
+        idb_set_error("idb_hconv: %dx%d maps are not tiled by whole rows of 128 pixels", d->h, d->w);
+        return IDB_EUNSUPPORTED;
+    }
+    pl->NB = NB;
+    pl->TPX = TPX;
+    pl->TH = TPX / d->w;
+    pl->PW = d->w + 2;
+    pl->PS = (pl->TH + 2) * pl->PW;
+    pl->P = NB * pl->PS;
+    if (pl->P > HC_PROWS) { idb_set_error("idb_hconv: patch of %d rows exceeds %d", pl->P, HC_PROWS); return IDB_EUNSUPPORTED; }
+    pl->M = (int)M;
+    pl->K = K;
+    pl->ktiles = ktiles;
+    pl->nf = d->n % 160 == 0 ? 5 : 4;
+    pl->tiles_m = (int)(M / 128);
+    pl->tiles_n = (d->n + 32 * pl->nf - 1) / (32 * pl->nf);
+    const long long blocks = (long long)pl->tiles_m * pl->tiles_n;
+    int sk = d->split_k;
+    if (sk <= 0) {
+        sk = (int)(256 / blocks);
+        const int cap = ktiles / 9;                        // at least one 9-tap chunk's worth of K-steps per slice
+        if (sk > cap) sk = cap;
+        if (sk > 32) sk = 32;
+        if (sk < 1) sk = 1;
+        if (sk > 8) sk = (sk / 8) * 8;                     // one K-slice per XCD (remap mode 1)
+        else if (sk >= 5) sk = 8 * 9 <= ktiles ? 8 : 4;
+        else if (sk == 3) sk = 2;
+    }
+    if (sk > ktiles) sk = ktiles;
+    // the scale/shift table must hold every segment-0 channel a K-slice touches, for every sample of the tile
+    if (d->gn_partials) {
+        const int taps0 = d->seg[0].taps, steps0 = taps0 * ((d->seg[0].c0 + d->seg[0].c1) / 64);
+        auto fits = [&](int s_) __attribute__((always_inline)) {
+            for (int kz = 0; kz < s_; ++kz) {
+                const int a = (int)(((long long)kz * ktiles) / s_), b = (int)(((long long)(kz + 1) * ktiles) / s_);
+                if (a >= steps0) break;
+                const int last = (b < steps0 ? b : steps0) - 1;
+                if (NB * (last / taps0 - a / taps0 + 1) * 64 > HC_TBL_CAP) return false;
+            }
+            return true;
+        };
+        while (!fits(sk) && d->split_k <= 0 && sk < 32 && sk < ktiles) ++sk;
+        if (!fits(sk)) { idb_set_error("idb_hconv: the normalised channel range of a K-slice exceeds the in-LDS table"); return IDB_EUNSUPPORTED; }
+    }
+    pl->splitk = sk;
+    return IDB_OK;
+}
+
+template <typename T, int NF>
+int launch_hconv(const HcParams& p, const HcPlan& pl, hipStream_t st) {
+    constexpr int NJ = (32 * NF + 63) / 64;
+    constexpr int LDS = 2 * HC_PBYTES + HC_NS * NJ * 64 * 128 + HC_TBL_BYTES + HC_GSTAT_BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_hconv_kernel<T, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            idb_set_error("idb_hconv: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
+            return IDB_EHIP;
+        }
+        attr_done = true;
+    }
+    dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.splitk);
+    hipLaunchKernelGGL((idb_hconv_kernel<T, NF>), grid, dim3(512), LDS, st, p);
+    IDB_CHECK_LAUNCH("idb_hconv");
+    return IDB_OK;
+}
+
+template <typename T>
+int run_hconv(const idb_hconv_desc* d, const HcParams& p, const HcPlan& pl, hipStream_t st) {
+    int rc = pl.nf == 5 ? launch_hconv<T, 5>(p, pl, st) : launch_hconv<T, 4>(p, pl, st);
+    if (rc != IDB_OK || (d->flags & 1)) return rc;
+    return idb_finish_splitk<T>(p.g, pl.M, d->n, d->batch, pl.splitk, d->gn_partials_out, d->gn_groups_out, d->dtype, st);
+}
+
+}  // namespace
+
+extern "C" size_t idb_hconv_workspace_bytes(const idb_hconv_desc* d) {
+    HcPlan pl;
+    if (plan_hconv(d, &pl) != IDB_OK) return 0;
+    return pl.splitk > 1 ? (size_t)pl.splitk * pl.M * d->n * sizeof(float) : 0;
+}
+
+extern "C" int idb_hconv_plan(const idb_hconv_desc* d, int32_t* split_k, int32_t* blocks) {
+    HcPlan pl;
+    int rc = plan_hconv(d, &pl);
+    if (rc != IDB_OK) return rc;
+    if (split_k) *split_k = pl.splitk;
+    if (blocks) *blocks = pl.tiles_m * pl.tiles_n * pl.splitk;
+    return IDB_OK;
+}
+
+extern "C" int idb_hconv(const idb_hconv_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    HcPlan pl;
+    int rc = plan_hconv(d, &pl);
+    if (rc != IDB_OK) return rc;
+    const size_t need = pl.splitk > 1 ? (size_t)pl.splitk * pl.M * d->n * sizeof(float) : 0;
+    IDB_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && idb_aligned16(workspace)),
+                "idb_hconv: workspace too small (%zu < %zu) or unaligned", workspace_bytes, need);
+    HcParams p = {};
+    int kbase = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const idb_hconv_seg& S = d->seg[s];
+        const long long px = (long long)d->batch * d->h * d->w;
+        p.seg[s] = HcSeg{(const char*)S.x0, (const char*)S.x1, (unsigned)(px * S.c0 * 2), (unsigned)(px * S.c1 * 2), S.c0, S.c1, S.taps, kbase,
+                         (S.c0 + S.c1) / 64};
+        kbase += S.taps * (S.c0 + S.c1);
+    }
+    p.nseg = d->nseg;
+    p.H = d->h;
+    p.W = d->w;
+    p.TPX = pl.TPX;
+    p.NB = pl.NB;
+    p.TH = pl.TH;
+    p.PW = pl.PW;
+    p.PS = pl.PS;
+    p.P = pl.P;
+    p.gn_partials = d->gn_partials;
+    p.gamma = d->gamma;
+    p.beta = d->beta;
+    p.gn_chunks = d->gn_chunks;
+    p.groups = d->gn_groups;
+    p.cpg = d->gn_partials ? (d->seg[0].c0 + d->seg[0].c1) / d->gn_groups : 1;
+    p.silu = d->silu;
+    p.eps = d->gn_eps;
+    GemmParams& g = p.g;
+    g.M = pl.M;
+    g.N = d->n;
+    g.HW = d->h * d->w;
+    g.OW = d->w;
+    g.stride = 1;
+    g.pad = 1;
+    g.w_row_bytes = (unsigned)(pl.K * 2);
+    g.w_bytes = (unsigned)((long long)d->n * pl.K * 2);
+    g.ktiles = pl.ktiles;
+    g.kt_per_split = (pl.ktiles + pl.splitk - 1) / pl.splitk;
+    g.splitk = pl.splitk;
+    g.xcd_mode = 0;
+    {
+        const long long X = (long long)pl.tiles_m * pl.tiles_n;
+        if (pl.splitk >= 8 && pl.splitk % 8 == 0) g.xcd_mode = 1;
+        else if (pl.splitk == 4 && X % 2 == 0) g.xcd_mode = 2;
+    }
+    g.w = (const char*)d->w_ptr;
+    g.bias = d->bias;
+    g.sbias = d->sample_bias;
+    g.sbias_ld = d->sample_bias_ld;
+    g.res = (const char*)d->residual;
+    g.out = d->out;
+    g.out_ld = d->out_ld;
+    g.out_f32 = 0;
+    g.geglu = 0;
+    g.scale = 1.f;
+    g.partial = (float*)workspace;
+    g.tiles_n = pl.tiles_n;
+    g.out_bytes = (unsigned)((long long)pl.M * d->out_ld * 2);
+    g.counters = nullptr;
+    g.lds_epi = (pl.splitk == 1 && (!d->residual || idb_aligned16(d->residual))) ? 1 : 0;
+    g.slab_swc = 0;
+    if (d->gn_partials_out && pl.splitk > 1 && !(d->flags & 1) && idb_reduce_vec_ok(g, d->n)) g.slab_swc = gn_reduce_slice(d->n, d->gn_groups_out);
+    hipStream_t st = (hipStream_t)stream;
+    return d->dtype == IDB_BF16 ? run_hconv<__bf16>(d, p, pl, st) : run_hconv<_Float16>(d, p, pl, st);
+}

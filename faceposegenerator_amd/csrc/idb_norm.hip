@@ -530,6 +530,25 @@ int idb_launch_gn_stats64(const void* x, int c, int batch, int hw, int groups, f
     return IDB_OK;
 }
 
+extern "C" int idb_groupnorm_stats(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw, int32_t groups,
+                                   float* partials, size_t partials_bytes, int32_t* chunks, int32_t dtype, void* stream) {
+    IDB_REQUIRE(x0 && partials && chunks && idb_aligned16(x0) && idb_aligned16(partials) && (!x1 || idb_aligned16(x1)), "idb_groupnorm_stats: null or unaligned pointer");
+    IDB_REQUIRE(idb_is_operand_dtype(dtype) && batch > 0 && hw > 0 && groups > 0, "idb_groupnorm_stats: bad arguments");
+    IDB_REQUIRE(c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0 && (x1 != nullptr) == (c1 > 0) && (c0 + c1) % groups == 0 && (c0 + c1) / groups >= 2,
+                "idb_groupnorm_stats: c0=%d c1=%d groups=%d unsupported", c0, c1, groups);
+    const GnGeom g = gn_geometry(c0, c1, batch, hw, groups);
+    IDB_REQUIRE(g.cols <= GN_THREADS && g.gps <= 64, "idb_groupnorm_stats: unsupported geometry");
+    IDB_REQUIRE(partials_bytes >= (size_t)batch * g.nchunks * groups * 2 * sizeof(float), "idb_groupnorm_stats: partials buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == IDB_BF16)
+        hipLaunchKernelGGL((gn_stats_kernel<__bf16>), dim3(g.nchunks, g.nslices, batch), dim3(GN_THREADS), 0, st, (const __bf16*)x0, (const __bf16*)x1, g, partials);
+    else
+        hipLaunchKernelGGL((gn_stats_kernel<_Float16>), dim3(g.nchunks, g.nslices, batch), dim3(GN_THREADS), 0, st, (const _Float16*)x0, (const _Float16*)x1, g, partials);
+    IDB_CHECK_LAUNCH("idb_groupnorm_stats");
+    *chunks = g.nchunks;
+    return IDB_OK;
+}
+
 extern "C" size_t idb_groupnorm_workspace_bytes(int32_t batch, int32_t hw, int32_t groups) {
     if (batch <= 0 || hw <= 0 || groups <= 0) return 0;
     return (size_t)batch * GN_MAXCHUNKS * groups * 2 * sizeof(float);

@@ -9,10 +9,12 @@ What is compared (measured values are printed, recorded in DESIGN.md section 2, 
     fp32 oracle run here on the host CPU, next to the SAME comparison for the oracle with the engine's rounding points
     emulated (oracle.ROUND): the engine must sit in the error class of its operand dtype, block by block.
 
-north_star states "latents within 1e-2 max-abs of the CPU fp32 reference".  On this synthetic-weight network the final
-latents have std ~6 and 16-bit storage cannot reach that bound (the emulated-rounding oracle, i.e. ANY implementation that
-stores f16 activations and weights — the reference's own `torch_dtype=torch.float16` run included — misses it by the same
-factor); the bounds below are therefore the measured ones, and the 1e-2 figure is reported as not met.
+north_star states "latents within 1e-2 max-abs of the CPU fp32 reference".  On this synthetic-weight network the latents grow
+to std 20 over the 30 steps (a trained model keeps them at std ~1), and in absolute terms 16-bit storage cannot reach that
+bound: the emulated-rounding oracle — i.e. ANY implementation that stores f16 weights and activations, the reference's own
+`torch_dtype=torch.float16` run included — ends at 0.165 max-abs, the HIP engine at 0.174 (f16).  Normalised by the latent
+scale the f16 figure is 8.7e-3 (< 1e-2); bf16 is 7.2e-2.  The bounds below are 1.5x the measured values; the absolute 1e-2
+figure is printed as NOT met.
 """
 import math
 import os
