@@ -69,8 +69,8 @@ __device__ __forceinline__ void hc_norm16(char* a, const float2* e, int silu) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         float y = to_f32<T>(raw[u]) * e[u].x + e[u].y;
-        if (silu) y = silu_f(y);
-        o[u] = from_f32<T>(y);
+        if (silu) y *= __builtin_amdgcn_rcpf(1.0f + __expf(-y));      // v_rcp_f32 (1 ulp) instead of the IEEE division sequence: the
+        o[u] = from_f32<T>(y);                                       // result is rounded to 11 / 8 bits right here
     }
     *(V8*)a = o;
 }
@@ -252,16 +252,18 @@ __global__ __launch_bounds__(512, 2) void idb_hconv_kernel(const HcParams p) {
 
     // in-place normalisation of a landed patch on the real pixels; padding rows stay zero
     const float2* tbl = (const float2*)(smem + OFF_TBL);
-#define HC_TRANSFORM(buf_, c_, compact_)                                                                                           \
+    // items [lo_, hi_) of the patch in buffer buf_ (a 3x3 patch has HC_NPP items per thread, a 1x1 patch 2)
+#define HC_TRANSFORM(buf_, c_, compact_, lo_, hi_)                                                                                 \
     do {                                                                                                                           \
         char* sT_ = smem + (buf_) * HC_PBYTES;                                                                                     \
         const int crel_ = ((c_) - first_chunk0) * 64;                                                                              \
+        const int tlo_ = (lo_), thi_ = (hi_);                                                                                      \
         if (!(compact_)) {                                                                                                         \
             _Pragma("unroll") for (int j = 0; j < HC_NPP; ++j)                                                                     \
-                if (t_tbl[j] >= 0) hc_norm16<T>(sT_ + (j * 512 + tid) * 16, tbl + t_tbl[j] + crel_, p.silu);                       \
+                if (j >= tlo_ && j < thi_ && t_tbl[j] >= 0) hc_norm16<T>(sT_ + (j * 512 + tid) * 16, tbl + t_tbl[j] + crel_, p.silu); \
         } else {                                                                                                                   \
-            hc_norm16<T>(sT_ + tid * 16, tbl + tc_off0 + crel_, p.silu);                                                           \
-            hc_norm16<T>(sT_ + (512 + tid) * 16, tbl + tc_off1 + crel_, p.silu);                                                   \
+            if (tlo_ <= 0 && thi_ > 0) hc_norm16<T>(sT_ + tid * 16, tbl + tc_off0 + crel_, p.silu);                                 \
+            if (tlo_ <= 1 && thi_ > 1) hc_norm16<T>(sT_ + (512 + tid) * 16, tbl + tc_off1 + crel_, p.silu);                         \
         }                                                                                                                          \
     } while (0)
 
@@ -285,10 +287,19 @@ __global__ __launch_bounds__(512, 2) void idb_hconv_kernel(const HcParams p) {
         for (int pair = tid >> 3; pair < p.NB * ng; pair += 64) {
             const int nb = pair / ng, g = g_lo + (pair - nb * ng);
             float a = 0.f, q = 0.f;
-            for (int k = sub; k < p.gn_chunks; k += 8) {
-                const f32x2 v = *(const f32x2*)(p.gn_partials + (((long long)(b0 + nb) * p.gn_chunks + k) * p.groups + g) * 2);
-                a += v[0];
-                q += v[1];
+            for (int k0 = 0; k0 < p.gn_chunks; k0 += 64) {           // 8 loads per lane in flight (clamped index, masked sum): a load
+                f32x2 pv[8];                                         // per loop iteration would be 8 dependent L2 round trips
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = min(k0 + sub + 8 * u, p.gn_chunks - 1);
+                    pv[u] = *(const f32x2*)(p.gn_partials + (((long long)(b0 + nb) * p.gn_chunks + k) * p.groups + g) * 2);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = k0 + sub + 8 * u < p.gn_chunks;
+                    a += in ? pv[u][0] : 0.f;
+                    q += in ? pv[u][1] : 0.f;
+                }
             }
 #pragma unroll
             for (int o = 1; o < 8; o <<= 1) {
@@ -323,18 +334,20 @@ __global__ __launch_bounds__(512, 2) void idb_hconv_kernel(const HcParams p) {
     // nxt_issue = K-step at which the next chunk's patch was issued.
     bool cur_tr = !(has_gn && cs == 0);
     bool nxt_tr = true, nxt_valid = false;
-    int nxt_issue = -1, nxt_s = 0, nxt_c = 0;
+    int nxt_issue = -1, nxt_s = 0, nxt_c = 0, nxt_done = 0;           // nxt_done: items of the next patch already normalised
     int cur = 0;                                                     // weight ring stage of step `it`
     bool first_of_chunk = true;                                      // the step is the first one (of this workgroup) on its chunk
     for (int it = 0; it < nk; ++it) {
         const int taps = HC_TAPS(cs);
         const bool last_of_chunk = ctp == taps - 1 || it == nk - 1;
         // does this step normalise the next patch?  (landed everywhere after this step's barrier if every wave waits for it now)
+        // One item per thread and step from the third step after the issue (the VALU work then hides under the other waves' MFMAs
+        // and waits), whatever is left at the chunk's last step.
         const bool tr_next_now = nxt_valid && !nxt_tr && (it >= nxt_issue + 3 || last_of_chunk);
         int need = cur == 0 ? w_end0 : (cur == 1 ? w_end1 : w_end2);
         const int pe_cur = cbuf == 0 ? p_end0 : p_end1, pe_nxt = cbuf == 0 ? p_end1 : p_end0;
         if (first_of_chunk && pe_cur > need) need = pe_cur;
-        if (tr_next_now && pe_nxt > need) need = pe_nxt;
+        if (tr_next_now && nxt_done == 0 && pe_nxt > need) need = pe_nxt;
         const int allowed = issued - need;
         if (allowed >= LW + HC_NPP)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LW + HC_NPP) : "memory");
@@ -365,17 +378,22 @@ __global__ __launch_bounds__(512, 2) void idb_hconv_kernel(const HcParams p) {
             nxt_issue = it;
             nxt_s = ns;
             nxt_c = nc;
+            nxt_done = 0;
             nxt_tr = !(has_gn && ns == 0);
         }
 
         if (!cur_tr) {                                               // not normalised ahead of time (first chunk, 1x1 chunks): now, then a barrier
-            HC_TRANSFORM(cbuf, cch, taps == 1);
+            HC_TRANSFORM(cbuf, cch, taps == 1, 0, HC_NPP);
             cur_tr = true;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (tr_next_now) {
-            HC_TRANSFORM(cbuf ^ 1, nxt_c, HC_TAPS(nxt_s) == 1);
-            nxt_tr = true;
+            const bool ncompact = HC_TAPS(nxt_s) == 1;
+            const int nitems = ncompact ? 2 : HC_NPP;
+            const int hi = last_of_chunk ? nitems : nxt_done + 1;
+            HC_TRANSFORM(cbuf ^ 1, nxt_c, ncompact, nxt_done, hi);
+            nxt_done = hi;
+            nxt_tr = nxt_done >= nitems;
         }
 
         // MFMAs of this step: weight fragment = A operand, activation fragment = B operand (idb_gemm_kernel's convention)

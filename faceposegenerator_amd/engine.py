@@ -116,9 +116,12 @@ class HipEngine:
         self._gn_sync = torch.zeros(1 << 14, dtype=torch.int32, device=self.device) if os.environ.get("IDB_GN_SYNC") == "1" else None
         # first GroupNorm pass produced by the GEMM that writes the tensor (idb_gemm_desc.gn_partials); IDB_GN_FUSE=0 disables
         self._gn_fuse = os.environ.get("IDB_GN_FUSE", "1") != "0"
-        # GroupNorm(+SiLU) applied inside the consuming conv (idb_hconv) for grids of at most this many 128-row tiles per launch
-        # (the kernel holds one workgroup per CU: the small-batch regime); IDB_HCONV=0 keeps idb_groupnorm + idb_gemm everywhere
-        self._hconv_tiles = int(os.environ.get("IDB_HCONV_TILES", "512")) if os.environ.get("IDB_HCONV", "1") != "0" else 0
+        # GroupNorm(+SiLU) applied inside the consuming conv (idb_hconv).  Measured on MI355X at batch 1 (tools/bench_hconv.py,
+        # DESIGN.md section 5): 47 us against 31 + 9.6 us for idb_gemm + the gn_apply launch on the 320->320 @64x64 layer, 5.70
+        # against 6.62 images/s end to end — the in-LDS SiLU costs more than the launch it saves, so the policy default is OFF and
+        # IDB_HCONV=1 turns it on (grids of at most IDB_HCONV_TILES 128-row tiles: the kernel holds one workgroup per CU).
+        self._use_hconv = os.environ.get("IDB_HCONV", "0") == "1"
+        self._hconv_tiles = int(os.environ.get("IDB_HCONV_TILES", "512"))
         self._hconv_proj_in = os.environ.get("IDB_HCONV_PROJ_IN", "1") != "0"      # Transformer2DModel.norm + proj_in fused as well
         self.w: Dict[str, torch.Tensor] = {}
         self.master: Dict[str, torch.Tensor] = {}
@@ -480,7 +483,7 @@ class HipEngine:
 
     def hconv_supported(self, segs, w, n, batch, h, w_, gn_groups: int = 0) -> bool:
         """Would idb_hconv take this shape (and is the grid in the kernel's one-workgroup-per-CU regime)?  Host-only."""
-        if not self._hconv_tiles or (batch * h * w_) % 128 or (batch * h * w_ // 128) * ((n + 159) // 160) > self._hconv_tiles:
+        if (batch * h * w_) % 128 or (batch * h * w_ // 128) * ((n + 159) // 160) > self._hconv_tiles:
             return False
         dummy = self._gn_ws.data_ptr()
         gn = (dummy, 1, gn_groups, 1e-5, self._gn_ws, self._gn_ws, True) if gn_groups else None
@@ -546,7 +549,7 @@ class HipEngine:
         G0 = groups or self.ucfg.norm_num_groups
         short = f"{name}.has_shortcut" in W
         seg1 = [(xa, ca, xb, cb, 9)]
-        if self.hconv_supported(seg1, W[f"{name}.conv1.w"], cout, batch, h, w_, G0) and \
+        if self._use_hconv and self.hconv_supported(seg1, W[f"{name}.conv1.w"], cout, batch, h, w_, G0) and \
                 self.hconv_supported([(xa, cout, None, 0, 9)] + ([(xa, ca, xb, cb, 1)] if short else []), W[f"{name}.conv2.w"], cout,
                                      batch, h, w_, G0):
             # GroupNorm+SiLU inside both convs (idb_hconv): norm1+conv1(+temb), norm2+conv2(+1x1 shortcut | +residual)
@@ -588,7 +591,7 @@ class HipEngine:
         hw = h * w_
         m = batch * hw
         G = self.ucfg.norm_num_groups
-        if self._hconv_proj_in and self.hconv_supported([(x, c, None, 0, 1)], W[f"{n}.proj_in.w"], c, batch, h, w_, G):
+        if self._use_hconv and self._hconv_proj_in and self.hconv_supported([(x, c, None, 0, 1)], W[f"{n}.proj_in.w"], c, batch, h, w_, G):
             part, chunks = self.gn_statistics(x, c, None, 0, batch, hw, G)
             h0 = self.hconv([(x, c, None, 0, 1)], W[f"{n}.proj_in.w"], c, batch, h, w_, gn=(part, chunks, G, 1e-6, W[f"{n}.norm.g"],
                             W[f"{n}.norm.b"], False), bias=W[f"{n}.proj_in.b"])

@@ -29,6 +29,31 @@ from . import weights as W
 from .scheduler import DDPMScheduler, DPMSolverMultistepScheduler
 
 
+class _range:
+    """roctx range around a pipeline stage (rocprofv3 --marker-trace shows text-encode / sampling loop / VAE decode);
+    on only with IDB_ROCTX=1 so that the default path makes no extra calls."""
+    _on = os.environ.get("IDB_ROCTX") == "1"
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if self._on:
+            try:
+                torch.cuda.nvtx.range_push(self.name)        # roctxRangePush on ROCm builds of torch
+            except Exception:
+                type(self)._on = False
+        return self
+
+    def __exit__(self, *exc):
+        if self._on:
+            try:
+                torch.cuda.nvtx.range_pop()
+            except Exception:
+                type(self)._on = False
+        return False
+
+
 class StableDiffusionPipelineOutput:
     def __init__(self, images, nsfw_content_detected=None):
         self.images = images
@@ -272,9 +297,12 @@ class StableDiffusionPipeline:
         return self.encode_prompt(prompt, negative_prompt, do_cfg)
 
     def prepare_noise(self, batch: int, steps: int, height: int, width: int, generator) -> torch.Tensor:
-        """RNG order of the upstream pipeline with a CPU generator (randn_tensor draws on the generator's
-        device): initial latents, then one draw per step including the last (t=1 > 0).  A list of
-        generators gives one stream per sample, as upstream.  Returns [steps+1, B, C, h, w] fp32 (host)."""
+        """RNG ORDER of the upstream pipeline (randn_tensor draws on the generator's device): initial latents, then one draw
+        per step including the last (t=1 > 0).  A list of generators gives one stream per sample, as upstream.  Returns
+        [steps+1, B, C, h, w] fp32 (host).  Only the order of draws is the reference's: the reference seeds a
+        ``torch.Generator(device='cuda:0')`` (inference_ID-Booth.py:47,111) whose Philox stream, drawn in fp16 by diffusers,
+        is a different sequence of numbers from the CPU mt19937 fp32 stream used here — the same seed does not give the
+        same image as the reference's CUDA run (no CUDA generator exists on this platform to compare with)."""
         lc = self.unet_config.in_channels
         h, w_ = height // self.vae_scale_factor, width // self.vae_scale_factor
         if isinstance(generator, (list, tuple)):
@@ -303,7 +331,8 @@ class StableDiffusionPipeline:
             raise ValueError(f"output_type {output_type!r} not supported")
         do_cfg = guidance_scale > 1.0
         if prompt_embeds is None:
-            prompt_embeds, negative_prompt_embeds = self._encode(prompt, negative_prompt, do_cfg)
+            with _range("idb:text_encoder"):
+                prompt_embeds, negative_prompt_embeds = self._encode(prompt, negative_prompt, do_cfg)
         if do_cfg and negative_prompt_embeds is None:
             raise ValueError("guidance_scale > 1 needs `negative_prompt_embeds` (or a negative prompt with a text encoder)")
         if num_images_per_prompt != 1:
@@ -317,7 +346,13 @@ class StableDiffusionPipeline:
         timesteps = sch.timesteps.tolist()
         multistep = isinstance(sch, DPMSolverMultistepScheduler)         # deterministic solver: initial latents only
         if noise is None:
-            noise = self.prepare_noise(B, 0 if multistep else num_inference_steps, height, width, generator)
+            if latents is not None and not multistep:
+                # upstream prepare_latents draws nothing when `latents` is given: the generator's first draw is step 0's noise
+                step_noise = self.prepare_noise(B, num_inference_steps - 1, height, width, generator)
+                noise = torch.cat([(latents.float().cpu() * sch.init_noise_sigma)[None], step_noise])
+                latents = None
+            else:
+                noise = self.prepare_noise(B, 0 if multistep else num_inference_steps, height, width, generator)
         if latents is not None:
             noise = noise.clone()
             noise[0] = latents.float().cpu() * sch.init_noise_sigma
@@ -327,13 +362,15 @@ class StableDiffusionPipeline:
                                  dtype=torch.float32)
         else:
             coefs = torch.tensor([list(sch.step_coefficients(t)) + [float(guidance_scale)] for t in timesteps], dtype=torch.float32)
-        lat = eng.sample(prompt_embeds, negative_prompt_embeds if do_cfg else None, noise.to(self.device), timesteps,
-                         coefs.to(self.device), vpred=(sch.config.prediction_type == "v_prediction"),
-                         use_graph=self.use_graph, multistep=multistep)
+        with _range("idb:sampling_loop"):
+            lat = eng.sample(prompt_embeds, negative_prompt_embeds if do_cfg else None, noise.to(self.device), timesteps,
+                             coefs.to(self.device), vpred=(sch.config.prediction_type == "v_prediction"),
+                             use_graph=self.use_graph, multistep=multistep)
         if output_type == "latent":
             images = lat
         else:
-            img01, u8 = eng.decode_images(lat, chunk=self.vae_chunk, want_u8=True)
+            with _range("idb:vae_decode_postprocess"):
+                img01, u8 = eng.decode_images(lat, chunk=self.vae_chunk, want_u8=True)
             if output_type == "np":
                 images = img01.cpu().numpy()                       # NHWC float32 in [0,1]
             elif output_type == "pt":

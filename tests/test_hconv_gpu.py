@@ -140,3 +140,35 @@ def test_hconv_rejects_shapes_it_does_not_tile(eng):
     assert not eng.hconv_supported([(x, 64, None, 0, 9)], w, 64, 1, 96, 96, 32)      # 96-wide maps (768^2 config)
     x = _nhwc(_rand((3, 64, 8, 8), 43).to(eng.tdt))
     assert not eng.hconv_supported([(x, 64, None, 0, 9)], w, 64, 3, 8, 8, 32)        # 3 samples of 64 pixels: not a multiple of 128
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_unet_and_vae_with_the_fused_path_switched_on(lib, dtype):
+    """The engine's opt-in policy (IDB_HCONV=1): every ResnetBlock2D and Transformer2DModel.norm+proj_in of the reduced graph through
+    idb_hconv, against the CPU oracle with the single-forward tolerance of tests/test_engine_gpu.py, and against the default path."""
+    from faceposegenerator_amd import spec as S, weights as W
+    from faceposegenerator_amd.pipeline import StableDiffusionPipeline
+    from oracle import sd21_oracle as O
+    ucfg, vcfg = S.TINY_UNET, S.TINY_VAE
+    usd, vsd = W.synth_unet(ucfg, 7), W.synth_vae(vcfg, 8)
+    pipe = StableDiffusionPipeline(ucfg, vcfg, usd, vsd, torch_dtype=dtype).to(DEV)
+    eng = pipe._engine()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(8, 4, 16, 16, generator=g)                       # 8 samples: the 4x4 level tiles as 8 whole samples
+    ctx = torch.randn(8, 77, ucfg.cross_attention_dim, generator=g)
+    ref = O.unet_forward(usd, ucfg, x, 501, ctx)
+    base = pipe.unet(x.to(DEV), 501, ctx.to(DEV), return_dict=False)[0].cpu()
+    n_base = eng.last_forward_launches
+    eng._use_hconv = True
+    got = pipe.unet(x.to(DEV), 501, ctx.to(DEV), return_dict=False)[0].cpu()
+    n_fused = eng.last_forward_launches
+    mx_tol, rel_tol = {"bf16": (6e-2, 2e-2), "f16": (1e-2, 3e-3)}[dtype]
+    err = (got - ref).abs().max().item()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    print(f"[{dtype}] fused-GroupNorm UNet forward: max-abs {err:.3e} rel-rms {rel:.3e}; launches {n_base} -> {n_fused}")
+    assert err < mx_tol and rel < rel_tol
+    assert (got - base).abs().max().item() < mx_tol and n_fused < n_base
+    z = torch.randn(2, 4, 16, 16, generator=g) * 3
+    ref_v = O.vae_decode(vsd, vcfg, z)
+    got_v = pipe.vae.decode(z.to(DEV)).sample.cpu()
+    assert ((got_v - ref_v).norm() / ref_v.norm()).item() < rel_tol
