@@ -27,6 +27,7 @@ EXPORTS = [
     "idb_timestep_sinusoid", "idb_linear_f32", "idb_conv_in",
     "idb_cfg_ddpm_step", "idb_postprocess",
     "idb_nhwc_to_nchw_f32", "idb_f32_nhwc_to_nchw", "idb_cast_f32", "idb_vae_sample", "idb_warp_affine_u8",
+    "idb_crop_resize_area_u8", "idb_conv2d_f32", "idb_maxpool2d_f32", "idb_softmax_pairs_f32",
 ]
 
 
@@ -109,6 +110,10 @@ def load() -> C.CDLL:
         "idb_cast_f32": (C.c_int, [vp, vp, i64, i32, vp]),
         "idb_vae_sample": (C.c_int, [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp]),
         "idb_warp_affine_u8": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
+        "idb_crop_resize_area_u8": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, f32, f32, vp]),
+        "idb_conv2d_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+        "idb_maxpool2d_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+        "idb_softmax_pairs_f32": (C.c_int, [vp, vp, i32, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing

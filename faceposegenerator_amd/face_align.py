@@ -2,9 +2,11 @@
 face-recognition training — 5 landmarks -> similarity transform onto the ArcFace 112x112 template -> warped crop
 (/root/reference/utils/detect_align_crop_data.py:135-197, ``estimate_norm`` + ``norm_crop``).
 
-The landmark DETECTOR of that script (facenet_pytorch MTCNN, :18-20, :99) is not built: the module and its weights are not
-available offline; callers pass the landmarks.  The warp runs on the GPU (``idb_warp_affine_u8``) directly on the sampler's
-uint8 NHWC output; the 5-point least-squares fit is host arithmetic on 10 numbers per face, as in the reference."""
+The landmark DETECTOR of that script (facenet_pytorch MTCNN, :18-20, :99) is ``faceposegenerator_amd.mtcnn.MTCNN`` (P/R/O-Net
+cascade on HIP kernels; its trained weights are not available offline, so tests use seeded synthetic ones):
+``landmarks = mtcnn.detect(batch, landmarks=True)[2]`` then ``norm_crop(batch, [l[0] for l in landmarks])``.  The warp runs on
+the GPU (``idb_warp_affine_u8``) directly on the sampler's uint8 NHWC output; the 5-point least-squares fit is host arithmetic
+on 10 numbers per face, as in the reference."""
 from __future__ import annotations
 
 import ctypes as C

@@ -265,6 +265,25 @@ int idb_cast_f32(const float* x, void* out, int64_t count, int32_t dtype, void* 
 int idb_warp_affine_u8(const uint8_t* src, int32_t batch, int32_t h, int32_t w, int32_t channels, const double* m_inv,
                        uint8_t* dst, int32_t out_h, int32_t out_w, int32_t border_value, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MTCNN face detector (facenet_pytorch P-Net / R-Net / O-Net as used at
+ * utils/detect_align_crop_data.py:18-20,99).  fp32 NCHW activations; the cascade's control logic (image pyramid, box generation,
+ * NMS, regression) is host code in faceposegenerator_amd/mtcnn.py.
+ *   idb_crop_resize_area_u8: out[k] = (F.interpolate(src[image_k, y0:y1, x0:x1], (out_h, out_w), mode="area") - sub) * mul for
+ *       boxes [n][5] = {image, y0, y1, x0, x1} (int32 on the device, exclusive ends, clipped by the caller); uint8 NHWC in,
+ *       fp32 [n][channels][out_h][out_w] out (upstream imresample + the (x - 127.5) / 128 normalisation)
+ *   idb_conv2d_f32: nn.Conv2d(cin, cout, (kh, kw)) (stride 1, no padding) + optional nn.PReLU(cout); also the dense layers
+ *       (a kernel as large as the map)
+ *   idb_maxpool2d_f32: nn.MaxPool2d(k, stride, ceil_mode=True) over `planes` = batch * channels maps
+ *   idb_softmax_pairs_f32: softmax over a channel pair, p1 = softmax(x[b][0:2][i])[1]
+ * ------------------------------------------------------------------------------------------ */
+int idb_crop_resize_area_u8(const uint8_t* src, int32_t batch, int32_t h, int32_t w, int32_t channels, const int32_t* boxes, int32_t n,
+                            float* out, int32_t out_h, int32_t out_w, float sub, float mul, void* stream);
+int idb_conv2d_f32(const float* x, const float* w, const float* bias, const float* prelu, float* y, int32_t batch, int32_t cin, int32_t h,
+                   int32_t w_, int32_t cout, int32_t kh, int32_t kw, void* stream);
+int idb_maxpool2d_f32(const float* x, float* y, int32_t planes, int32_t h, int32_t w, int32_t k, int32_t stride, void* stream);
+int idb_softmax_pairs_f32(const float* x, float* p1, int32_t batch, int32_t hw, void* stream);
+
 int idb_vae_sample(const float* moments, const float* noise, float scale, float* latents, float* mean_out,
                    float* logvar_out, int32_t batch, int32_t channels, int32_t hw, void* stream);
 
