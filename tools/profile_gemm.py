@@ -12,7 +12,7 @@ from faceposegenerator_amd.engine import HipEngine
 
 be = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-eng = HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, "cuda:0", "bf16")
+eng = HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, "cuda:0", os.environ.get("IDB_DTYPE", "f16"))
 side, cin, cout = 64, 320, 320
 x = torch.randn(be * side * side, cin, device=eng.device).to(eng.tdt)
 w = (torch.randn(cout, 9 * cin, device=eng.device) * (9 * cin) ** -0.5).to(eng.tdt)
