@@ -123,6 +123,7 @@ class HipEngine:
         self._use_hconv = os.environ.get("IDB_HCONV", "0") == "1"
         self._hconv_tiles = int(os.environ.get("IDB_HCONV_TILES", "512"))
         self._hconv_proj_in = os.environ.get("IDB_HCONV_PROJ_IN", "1") != "0"      # Transformer2DModel.norm + proj_in fused as well
+        self._hconv_resnet = os.environ.get("IDB_HCONV_RESNET", "1") != "0"        # ResnetBlock2D norm1+conv1 / norm2+conv2
         self.w: Dict[str, torch.Tensor] = {}
         self.master: Dict[str, torch.Tensor] = {}
         self.tproj_off: Dict[str, int] = {}
@@ -549,7 +550,7 @@ class HipEngine:
         G0 = groups or self.ucfg.norm_num_groups
         short = f"{name}.has_shortcut" in W
         seg1 = [(xa, ca, xb, cb, 9)]
-        if self._use_hconv and self.hconv_supported(seg1, W[f"{name}.conv1.w"], cout, batch, h, w_, G0) and \
+        if self._use_hconv and self._hconv_resnet and self.hconv_supported(seg1, W[f"{name}.conv1.w"], cout, batch, h, w_, G0) and \
                 self.hconv_supported([(xa, cout, None, 0, 9)] + ([(xa, ca, xb, cb, 1)] if short else []), W[f"{name}.conv2.w"], cout,
                                      batch, h, w_, G0):
             # GroupNorm+SiLU inside both convs (idb_hconv): norm1+conv1(+temb), norm2+conv2(+1x1 shortcut | +residual)
