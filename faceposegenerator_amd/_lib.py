@@ -28,6 +28,7 @@ EXPORTS = [
     "idb_cfg_ddpm_step", "idb_postprocess",
     "idb_nhwc_to_nchw_f32", "idb_f32_nhwc_to_nchw", "idb_cast_f32", "idb_vae_sample", "idb_warp_affine_u8",
     "idb_crop_resize_area_u8", "idb_conv2d_f32", "idb_maxpool2d_f32", "idb_softmax_pairs_f32",
+    "idb_quantize_fp8", "idb_pack_weight_fp8", "idb_gemm_fp8",
 ]
 
 
@@ -60,6 +61,14 @@ class HconvDesc(C.Structure):
                 ("w_ptr", C.c_void_p), ("bias", C.c_void_p), ("sample_bias", C.c_void_p), ("sample_bias_ld", C.c_int32),
                 ("residual", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int32), ("split_k", C.c_int32),
                 ("gn_partials_out", C.c_void_p), ("gn_groups_out", C.c_int32), ("flags", C.c_int32)]
+
+
+class GemmFp8Desc(C.Structure):
+    _fields_ = [("out_dtype", C.c_int32), ("batch", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("stride", C.c_int32),
+                ("n", C.c_int32), ("x", C.c_void_p), ("channels", C.c_int32), ("taps", C.c_int32), ("in_h", C.c_int32),
+                ("in_w", C.c_int32), ("upsample", C.c_int32), ("x_scale", C.c_float), ("w", C.c_void_p), ("w_scale", C.c_void_p),
+                ("bias", C.c_void_p), ("sample_bias", C.c_void_p), ("sample_bias_ld", C.c_int32), ("residual", C.c_void_p),
+                ("out", C.c_void_p), ("out_ld", C.c_int32)]
 
 
 class IdbError(RuntimeError):
@@ -114,6 +123,9 @@ def load() -> C.CDLL:
         "idb_conv2d_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
         "idb_maxpool2d_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "idb_softmax_pairs_f32": (C.c_int, [vp, vp, i32, i32, vp]),
+        "idb_quantize_fp8": (C.c_int, [vp, vp, i64, f32, i32, vp]),
+        "idb_pack_weight_fp8": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+        "idb_gemm_fp8": (C.c_int, [C.POINTER(GemmFp8Desc), vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing

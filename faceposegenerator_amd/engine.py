@@ -520,6 +520,41 @@ class HipEngine:
                         "bytes": 2.0 * (sum(m * (c0 + c1) for (_, c0, _, c1, _) in segs) + n * k_total + m * n)})
         return out
 
+    # ---- fp8 (e4m3) GEMM path: kernel level of BASELINE configs[4] (idb_gemm8.hip) -------------------------------------------
+    def quantize_fp8(self, x: torch.Tensor, scale: float) -> torch.Tensor:
+        """operand-dtype tensor -> uint8 storage of e4m3(x / scale) (saturating)."""
+        out = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
+        L.check(self.lib.idb_quantize_fp8(x.data_ptr(), out.data_ptr(), x.numel(), 1.0 / float(scale), self.dt, _stream()), "idb_quantize_fp8")
+        return out
+
+    def pack_weight_fp8(self, w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """torch Conv2d [cout,cin,kh,kw] / Linear [out,in] fp32 -> (fp8 [cout][taps][cin padded to 128] as uint8, scales [cout] fp32)."""
+        w4 = w if w.ndim == 4 else w[:, :, None, None]
+        cout, cin, kh, kw = w4.shape
+        src = self._f32(w4)
+        cpad = (cin + 127) // 128 * 128
+        dst = torch.empty((cout, kh * kw * cpad), dtype=torch.uint8, device=self.device)
+        scales = torch.empty((cout,), dtype=torch.float32, device=self.device)
+        L.check(self.lib.idb_pack_weight_fp8(src.data_ptr(), dst.data_ptr(), scales.data_ptr(), cout, cin, kh * kw, _stream()), "idb_pack_weight_fp8")
+        return dst, scales
+
+    def gemm_fp8(self, x8: torch.Tensor, x_scale: float, channels: int, taps: int, in_h: int, in_w: int, w8: torch.Tensor, w_scale: torch.Tensor,
+                 n: int, batch: int, oh: int, ow: int, bias=None, sbias=None, residual=None, stride: int = 1, upsample: int = 0,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        m = batch * oh * ow
+        if out is None:
+            out = self.arena.alloc((m, n), self.tdt)
+        d = L.GemmFp8Desc()
+        d.out_dtype, d.batch, d.out_h, d.out_w, d.stride, d.n = self.dt, batch, oh, ow, stride, n
+        d.x, d.channels, d.taps, d.in_h, d.in_w, d.upsample, d.x_scale = x8.data_ptr(), channels, taps, in_h, in_w, upsample, float(x_scale)
+        d.w, d.w_scale, d.bias = w8.data_ptr(), w_scale.data_ptr(), _ptr(bias)
+        if sbias is not None:
+            d.sample_bias = sbias[0].data_ptr() + 4 * sbias[1]
+            d.sample_bias_ld = sbias[2]
+        d.residual, d.out, d.out_ld = _ptr(residual), out.data_ptr(), out.shape[-1]
+        L.check(self.lib.idb_gemm_fp8(C.byref(d), _stream()), "idb_gemm_fp8")
+        return out
+
     def layernorm(self, x, rows, c, gamma, beta) -> torch.Tensor:
         out = self.arena.alloc((rows, c), self.tdt)
         L.check(self.lib.idb_layernorm(x.data_ptr(), out.data_ptr(), rows, c, 1e-5, gamma.data_ptr(), beta.data_ptr(),

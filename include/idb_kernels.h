@@ -284,6 +284,34 @@ int idb_conv2d_f32(const float* x, const float* w, const float* bias, const floa
 int idb_maxpool2d_f32(const float* x, float* y, int32_t planes, int32_t h, int32_t w, int32_t k, int32_t stride, void* stream);
 int idb_softmax_pairs_f32(const float* x, float* p1, int32_t batch, int32_t hw, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3) implicit GEMM on v_mfma_scale_f32_16x16x128_f8f6f4 — BASELINE configs[4] "fp8 MFMA weight path" (the 768x768
+ * v-prediction checkpoint selected at inference_ID-Booth.py:63-64,103), kernel level: out[m][n] = x_scale * w_scale[n] *
+ * sum_k x8[m][k] * w8[n][k] (+ bias, per-sample bias, residual), both operands 8-bit, fp32 accumulation, operand-dtype output.
+ * One source: NHWC fp8 [batch][in_h][in_w][channels] (taps 9: 3x3, padding 1; taps 1: the pixel itself), channels % 64 == 0.
+ *   idb_quantize_fp8: out8 = e4m3(x * inv_scale), saturating at +-448 (x: bf16/f16, count % 8 == 0)
+ *   idb_pack_weight_fp8: fp32 torch layout [cout][cin][ktaps] -> fp8 [cout][ktaps][cin rounded up to 128] (zero columns) with one
+ *       scale per output channel, scales[n] = absmax(row n) / 448
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t out_dtype;            /* IDB_BF16 / IDB_F16: dtype of `out` and `residual` */
+    int32_t batch, out_h, out_w, stride, n;
+    const void* x;                /* fp8 e4m3 NHWC */
+    int32_t channels, taps, in_h, in_w, upsample;
+    float x_scale;                /* real value = x_scale * fp8 value (per tensor) */
+    const void* w;                /* idb_pack_weight_fp8 layout */
+    const float* w_scale;         /* [n] */
+    const float* bias;
+    const float* sample_bias;
+    int32_t sample_bias_ld;
+    const void* residual;
+    void* out;
+    int32_t out_ld;
+} idb_gemm_fp8_desc;
+int idb_quantize_fp8(const void* x, void* out, int64_t count, float inv_scale, int32_t dtype, void* stream);
+int idb_pack_weight_fp8(const float* src, void* dst, float* scales, int32_t cout, int32_t cin, int32_t ktaps, void* stream);
+int idb_gemm_fp8(const idb_gemm_fp8_desc* d, void* stream);
+
 int idb_vae_sample(const float* moments, const float* noise, float scale, float* latents, float* mean_out,
                    float* logvar_out, int32_t batch, int32_t channels, int32_t hw, void* stream);
 

@@ -6,13 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from faceposegenerator_amd import spec as S
 from faceposegenerator_amd.engine import HipEngine
-eng = HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, "cuda:0", "bf16")
+eng = HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, "cuda:0", os.environ.get("IDB_DTYPE", "f16"))
 dev = eng.device
 be = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 shapes = [(64, 320, 320), (64, 640, 320), (64, 960, 320), (32, 640, 640), (32, 1280, 640), (32, 320, 640), (16, 1280, 1280), (16, 2560, 1280),
           (8, 1280, 1280), (8, 2560, 1280), (16, 640, 1280), (64, 512, 512), (128, 256, 256)]
 combos = [(0, 0), (16, 1), (18, 1), (18, 2), (18, 3), (18, 4), (18, 6), (18, 8), (18, 12), (18, 16), (18, 24), (17, 4), (17, 8), (17, 16), (19, 2), (19, 4), (19, 8)]
-if be >= 8:
+if os.environ.get("IDB_COMBOS"):        # e.g. IDB_COMBOS="0:0,6:2,6:4,8:4,8:8"  (tile:split_k)
+    combos = [tuple(int(v) for v in c.split(":")) for c in os.environ["IDB_COMBOS"].split(",")]
+elif be >= 8:
     combos = [(0, 0), (8, 1), (18, 1), (28, 1), (9, 1), (19, 1), (29, 1), (16, 1), (26, 1)]
 for (side, cin, cout) in shapes:
     m, k = be * side * side, 9 * cin
