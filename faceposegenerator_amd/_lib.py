@@ -28,7 +28,7 @@ EXPORTS = [
     "idb_cfg_ddpm_step", "idb_postprocess",
     "idb_nhwc_to_nchw_f32", "idb_f32_nhwc_to_nchw", "idb_cast_f32", "idb_vae_sample", "idb_warp_affine_u8",
     "idb_crop_resize_area_u8", "idb_conv2d_f32", "idb_maxpool2d_f32", "idb_softmax_pairs_f32",
-    "idb_quantize_fp8", "idb_pack_weight_fp8", "idb_gemm_fp8",
+    "idb_quantize_fp8", "idb_pack_weight_fp8", "idb_gemm_fp8", "idb_groupnorm_fp8",
 ]
 
 
@@ -126,6 +126,7 @@ def load() -> C.CDLL:
         "idb_quantize_fp8": (C.c_int, [vp, vp, i64, f32, i32, vp]),
         "idb_pack_weight_fp8": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "idb_gemm_fp8": (C.c_int, [C.POINTER(GemmFp8Desc), vp]),
+        "idb_groupnorm_fp8": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, f32, i32, vp, sz, vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing

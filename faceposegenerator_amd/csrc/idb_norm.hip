@@ -129,7 +129,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* x0, const
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* x0, const T* x1, GnGeom g, const float* partial,
                                                               const float* gamma, const float* beta, float eps, int silu,
-                                                              T* out, int pix_per_block) {
+                                                              T* out, int pix_per_block, float out8 = 0.f) {
     __shared__ float gmean[64], grstd[64];
     const int tid = threadIdx.x;
     const int slice = blockIdx.y, b = blockIdx.z;
@@ -197,13 +197,25 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* x0, const
             const int p = pb + u * g.PR;
             if (p < p1) {
                 typename Op<T>::v8 o;
+                float yv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float y = to_f32<T>(raw[u][e]) * ks[e] + kh[e];
                     if (silu) y = silu_f(y);
+                    yv[e] = y;
                     o[e] = from_f32<T>(y);
                 }
-                *(typename Op<T>::v8*)(out + ((long long)b * g.HW + p) * g.C + c) = o;
+                if (out8 > 0.f) {                       // fp8 e4m3 output (idb_groupnorm_fp8): y * out8, saturating, 8 bytes per thread
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) yv[e] = fminf(fmaxf(yv[e] * out8, -448.f), 448.f);
+                    unsigned lo = __builtin_amdgcn_cvt_pk_fp8_f32(yv[0], yv[1], 0u, false);
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(yv[2], yv[3], lo, true);
+                    unsigned hi = __builtin_amdgcn_cvt_pk_fp8_f32(yv[4], yv[5], 0u, false);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(yv[6], yv[7], hi, true);
+                    *(u32x2*)((unsigned char*)out + ((long long)b * g.HW + p) * g.C + c) = (u32x2){lo, hi};
+                } else {
+                    *(typename Op<T>::v8*)(out + ((long long)b * g.HW + p) * g.C + c) = o;
+                }
             }
         }
     }
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int cols) {
 template <typename T>
 int run_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
                   const float* gamma, const float* beta, int silu, void* out, void* ws, int* sync, int sync_len, const float* pin,
-                  int pin_chunks, hipStream_t st) {
+                  int pin_chunks, hipStream_t st, float out8 = 0.f) {
     GnGeom g = gn_geometry(c0, c1, batch, hw, groups);
     if (pin) {                                   // statistics came with the tensor (idb_gemm_desc.gn_partials): normalise only
         g.nchunks = pin_chunks;
@@ -474,7 +486,7 @@ int run_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int
         if (ppb < g.PR * 2) ppb = g.PR * 2;
         const int nblk = (hw + ppb - 1) / ppb;
         hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, g.nslices, batch), dim3(GN_THREADS), 0, st, (const T*)x0, (const T*)x1, g,
-                           pin, gamma, beta, eps, silu, (T*)out, ppb);
+                           pin, gamma, beta, eps, silu, (T*)out, ppb, out8);
         IDB_CHECK_LAUNCH("idb_groupnorm(apply)");
         return IDB_OK;
     }
@@ -506,7 +518,7 @@ int run_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int
     if (ppb < g.PR * 2) ppb = g.PR * 2;
     const int nblk = (hw + ppb - 1) / ppb;
     hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nblk, g.nslices, batch), dim3(GN_THREADS), 0, st, (const T*)x0,
-                       (const T*)x1, g, (const float*)ws, gamma, beta, eps, silu, (T*)out, ppb);
+                       (const T*)x1, g, (const float*)ws, gamma, beta, eps, silu, (T*)out, ppb, out8);
     IDB_CHECK_LAUNCH("idb_groupnorm(apply)");
     return IDB_OK;
 }
@@ -584,6 +596,27 @@ extern "C" int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t
                                        partials_chunks, st)
                : run_groupnorm<_Float16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out, workspace, sync, sync_len, partials_in,
                                          partials_chunks, st);
+}
+
+extern "C" int idb_groupnorm_fp8(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw, int32_t groups, float eps,
+                                 const float* gamma, const float* beta, int32_t silu, void* out8, float out_inv_scale, int32_t dtype,
+                                 void* workspace, size_t workspace_bytes, const float* partials_in, int32_t partials_chunks, void* stream) {
+    IDB_REQUIRE(out_inv_scale > 0.f && out8 && (((uintptr_t)out8) & 7) == 0, "idb_groupnorm_fp8: out_inv_scale must be > 0, out 8-byte aligned");
+    IDB_REQUIRE(idb_is_operand_dtype(dtype) && x0 && gamma && beta && idb_aligned16(x0) && idb_aligned16(gamma) && idb_aligned16(beta), "idb_groupnorm_fp8: bad pointers / dtype");
+    IDB_REQUIRE(batch > 0 && hw > 0 && groups > 0 && c0 > 0 && c1 >= 0 && (c1 == 0) == (x1 == nullptr) && (c1 == 0 || idb_aligned16(x1)), "idb_groupnorm_fp8: bad dims");
+    const int C = c0 + c1;
+    IDB_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0 && C % groups == 0 && C / groups >= 2, "idb_groupnorm_fp8: channels %d+%d / groups %d unsupported", c0, c1, groups);
+    {
+        const GnGeom g = gn_geometry(c0, c1, batch, hw, groups);
+        IDB_REQUIRE(g.cols <= GN_THREADS && g.gps <= 64 && batch <= 65535 && g.nslices <= 65535, "idb_groupnorm_fp8: unsupported geometry");
+    }
+    IDB_REQUIRE(workspace && workspace_bytes >= idb_groupnorm_workspace_bytes(batch, hw, groups), "idb_groupnorm_fp8: workspace too small");
+    IDB_REQUIRE(!partials_in || (c1 == 0 && hw % 64 == 0 && partials_chunks == hw / 64 && partials_chunks <= GN_MAXCHUNKS), "idb_groupnorm_fp8: bad partials_in");
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == IDB_BF16 ? run_groupnorm<__bf16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out8, workspace, nullptr, 0, partials_in,
+                                                     partials_chunks, st, out_inv_scale)
+                             : run_groupnorm<_Float16>(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, silu, out8, workspace, nullptr, 0, partials_in,
+                                                       partials_chunks, st, out_inv_scale);
 }
 
 extern "C" int idb_layernorm(const void* x, void* out, int64_t rows, int32_t c, float eps, const float* gamma,

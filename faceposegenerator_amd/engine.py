@@ -99,8 +99,12 @@ class HipEngine:
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         L.check(self.lib.idb_device_check(self.device.index or 0), "idb_device_check")
-        if dtype not in ("bf16", "f16"):
-            raise ValueError("dtype must be 'bf16' or 'f16'")
+        if dtype not in ("bf16", "f16", "fp8"):
+            raise ValueError("dtype must be 'bf16', 'f16' or 'fp8'")
+        # "fp8" (BASELINE configs[4]): the 3x3 convolutions of the UNet's ResnetBlock2Ds run on the fp8 MFMA path — GroupNorm+SiLU
+        # writes e4m3 activations with one fixed scale, weights are e4m3 with a scale per output channel (idb_gemm_fp8) — and
+        # everything else (attention, projections, residual stream, VAE) is the f16 path.
+        self.fp8 = dtype == "fp8"
         self.dtype_name = dtype
         self.dt = L.IDB_BF16 if dtype == "bf16" else L.IDB_F16
         self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
@@ -176,9 +180,14 @@ class HipEngine:
         w[f"{name}.conv1.b"] = self._f32(sd[f"{name}.conv1.bias"])
         w2 = self._pack_conv(sd[f"{name}.conv2.weight"])
         b2 = self._f32(sd[f"{name}.conv2.bias"])
+        if self.fp8 and has_temb:                       # UNet resnets: e4m3 copies of the two 3x3 convs, the 1x1 shortcut stays f16
+            w[f"{name}.conv1.w8"], w[f"{name}.conv1.s8"] = self.pack_weight_fp8(sd[f"{name}.conv1.weight"])
+            w[f"{name}.conv2.w8"], w[f"{name}.conv2.s8"] = self.pack_weight_fp8(sd[f"{name}.conv2.weight"])
         if f"{name}.conv_shortcut.weight" in sd:
             ws = sd[f"{name}.conv_shortcut.weight"]
             ws = self._pack_mat(ws.reshape(ws.shape[0], ws.shape[1]))
+            if self.fp8 and has_temb:
+                w[f"{name}.sc.w"] = ws
             w2 = torch.cat([w2, ws], dim=1).contiguous()          # [Cout][9*Cout + Cin]
             b2 = b2 + self._f32(sd[f"{name}.conv_shortcut.bias"])
             w[f"{name}.has_shortcut"] = torch.ones(1)
@@ -446,6 +455,30 @@ class HipEngine:
             self.arena.free(st[0])
         return out
 
+    X8_SCALE = 8.0 / 448.0        # fixed scale of the e4m3 GroupNorm+SiLU outputs (silu of a normalised value: |y| <~ 6; saturates at 8)
+
+    def groupnorm_fp8(self, x0, c0, x1, c1, batch, hw, gamma, beta, eps, silu, groups=None) -> torch.Tensor:
+        groups = groups or self.ucfg.norm_num_groups
+        out = self.arena.alloc((batch * hw, c0 + c1), torch.uint8)
+        need = self.lib.idb_groupnorm_workspace_bytes(batch, hw, groups)
+        if need > self._gn_ws.numel():
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("GroupNorm workspace would grow during graph capture")
+            self._retired.append(self._gn_ws)
+            self._gn_ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
+        pin, pin_chunks = None, 0
+        st = getattr(x0, "_gn", None)
+        if st is not None:
+            x0._gn = None
+            if x1 is None and st[1] * 64 == hw and st[2] == groups:
+                pin, pin_chunks = st[0], st[1]
+        L.check(self.lib.idb_groupnorm_fp8(x0.data_ptr(), c0, _ptr(x1), c1, batch, hw, groups, eps, gamma.data_ptr(), beta.data_ptr(), int(silu),
+                                           out.data_ptr(), 1.0 / self.X8_SCALE, self.dt, self._gn_ws.data_ptr(), self._gn_ws.numel(), _ptr(pin),
+                                           pin_chunks, _stream()), "idb_groupnorm_fp8")
+        if st is not None:
+            self.arena.free(st[0])
+        return out
+
     def gn_statistics(self, x0, c0, x1, c1, batch, hw, groups):
         """(partials [batch][chunks][groups][2] fp32, chunks) of GroupNorm(groups) over cat[x0, x1]: taken from the launch that
         produced x0 when it emitted them (``_gn``), else one idb_groupnorm_stats launch."""
@@ -601,6 +634,27 @@ class HipEngine:
                              gn_stats=G0 if out_stats else 0)
             self.arena.free(part)
             self.arena.free(h1)
+            return out
+        if self.fp8 and f"{name}.conv1.w8" in W:
+            # fp8 MFMA path: GroupNorm+SiLU -> e4m3, conv on v_mfma_scale_f32_16x16x128_f8f6f4; the 1x1 shortcut over the raw inputs
+            # stays an f16 GEMM whose result enters the second conv as its residual
+            sb = None if sbias is None else (sbias[0], sbias[1] + self.tproj_off[name], sbias[2])
+            n1 = self.groupnorm_fp8(xa, ca, xb, cb, batch, h * w_, W[f"{name}.gn1.g"], W[f"{name}.gn1.b"], eps, True, groups)
+            h1 = self.gemm_fp8(n1, self.X8_SCALE, cin, 9, h, w_, W[f"{name}.conv1.w8"], W[f"{name}.conv1.s8"], cout, batch, h, w_,
+                               bias=W[f"{name}.conv1.b"], sbias=sb)
+            self.arena.free(n1)
+            n2 = self.groupnorm_fp8(h1, cout, None, 0, batch, h * w_, W[f"{name}.gn2.g"], W[f"{name}.gn2.b"], eps, True, groups)
+            self.arena.free(h1)
+            if short:
+                srcs = [(xa, ca, 1, h, w_, 0)] + ([(xb, cb, 1, h, w_, 0)] if xb is not None else [])
+                res = self.gemm(srcs, W[f"{name}.sc.w"], cout, batch, h, w_)
+            else:
+                res = xa
+            out = self.gemm_fp8(n2, self.X8_SCALE, cout, 9, h, w_, W[f"{name}.conv2.w8"], W[f"{name}.conv2.s8"], cout, batch, h, w_,
+                                bias=W[f"{name}.conv2.b"], residual=res)
+            self.arena.free(n2)
+            if short:
+                self.arena.free(res)
             return out
         n1 = self.groupnorm(xa, ca, xb, cb, batch, h * w_, W[f"{name}.gn1.g"], W[f"{name}.gn1.b"], eps, True, groups)
         sb = None if sbias is None else (sbias[0], sbias[1] + self.tproj_off[name], sbias[2])

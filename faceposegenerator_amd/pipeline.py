@@ -139,9 +139,10 @@ class StableDiffusionPipeline:
         self.scheduler = scheduler or DDPMScheduler(S.SchedulerConfig(prediction_type=unet_config.prediction_type))
         # f16 is the reference's operand dtype (torch_dtype=torch.float16, inference_ID-Booth.py:103) and the default here: same MFMA
         # rate as bf16, 11 instead of 8 significant bits; bf16 stays selectable
-        self.dtype_name = {None: "f16", torch.bfloat16: "bf16", torch.float16: "f16", "bf16": "bf16", "f16": "f16"}.get(torch_dtype)
+        self.dtype_name = {None: "f16", torch.bfloat16: "bf16", torch.float16: "f16", "bf16": "bf16", "f16": "f16", "fp8": "fp8",
+                           getattr(torch, "float8_e4m3fn", "fp8"): "fp8"}.get(torch_dtype)
         if self.dtype_name is None:
-            raise ValueError(f"torch_dtype {torch_dtype} unsupported: use torch.bfloat16 or torch.float16")
+            raise ValueError(f"torch_dtype {torch_dtype} unsupported: use torch.bfloat16, torch.float16 or 'fp8' (e4m3 resnet convs)")
         self.device = torch.device("cpu")
         self._eng = None
         self._lora = None

@@ -309,6 +309,11 @@ typedef struct {
     int32_t out_ld;
 } idb_gemm_fp8_desc;
 int idb_quantize_fp8(const void* x, void* out, int64_t count, float inv_scale, int32_t dtype, void* stream);
+/* idb_groupnorm (two-launch form) writing its output as fp8 e4m3 of y * out_inv_scale, saturating: the activation operand of
+ * idb_gemm_fp8 straight from the normalisation — GroupNorm+SiLU outputs are bounded, so a fixed per-tensor scale serves. */
+int idb_groupnorm_fp8(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw, int32_t groups, float eps,
+                      const float* gamma, const float* beta, int32_t silu, void* out8, float out_inv_scale, int32_t dtype,
+                      void* workspace, size_t workspace_bytes, const float* partials_in, int32_t partials_chunks, void* stream);
 int idb_pack_weight_fp8(const float* src, void* dst, float* scales, int32_t cout, int32_t cin, int32_t ktaps, void* stream);
 int idb_gemm_fp8(const idb_gemm_fp8_desc* d, void* stream);
 

@@ -50,6 +50,27 @@ def _r(kind: str, t: Tensor) -> Tensor:
     return t if ROUND is None else ROUND(kind, t)
 
 
+# Second hook, for the fp8 path (BASELINE configs[4]): applied INSTEAD of ROUND to the GroupNorm+SiLU output that feeds a 3x3 conv of a
+# UNet ResnetBlock2D (the HIP engine writes that tensor as e4m3 straight from fp32).  ``fp8_quantize`` / ``fp8_weights`` are the
+# emulation of the engine's quantisers: one fixed scale for the activations, absmax / 448 per output channel for the weights.
+ROUND_CONV_IN = None
+
+
+def fp8_quantize(t: Tensor, scale: float) -> Tensor:
+    return (t * (1.0 / scale)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
+
+
+def fp8_weights(sd: SD) -> SD:
+    """State dict with the conv1 / conv2 weights of every UNet ResnetBlock2D replaced by their dequantised e4m3 form."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if ".resnets." in k and k.endswith((".conv1.weight", ".conv2.weight")):
+            s_ = v.flatten(1).abs().amax(1) / 448.0
+            s_ = torch.where(s_ > 0, s_, torch.ones_like(s_))
+            out[k] = (v * (1.0 / s_)[:, None, None, None]).to(torch.float8_e4m3fn).float() * s_[:, None, None, None]
+    return out
+
+
 # ----------------------------------------------------------------------------------------
 # embeddings  (diffusers models/embeddings.py: get_timestep_embedding, flip_sin_to_cos=True,
 # downscale_freq_shift=0, max_period=10000)
@@ -101,15 +122,16 @@ def merge_lora(sd: SD, lora: SD, scale: float = 1.0) -> SD:
 # UNet building blocks
 # ----------------------------------------------------------------------------------------
 def resnet_block(sd: SD, p: str, x: Tensor, temb: Optional[Tensor], groups: int, eps: float) -> Tensor:
+    fp8_in = ROUND_CONV_IN is not None and temb is not None          # UNet resnets only (the VAE's have no temb)
     h = F.group_norm(x, groups, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
-    h = _r("act", F.silu(h))
+    h = ROUND_CONV_IN(F.silu(h)) if fp8_in else _r("act", F.silu(h))
     h = F.conv2d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
     if temb is not None:
         t = F.linear(F.silu(temb), sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"])
         h = h + t[:, :, None, None]
     h = _r("act", h)
     h = F.group_norm(h, groups, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps)
-    h = _r("act", F.silu(h))
+    h = ROUND_CONV_IN(F.silu(h)) if fp8_in else _r("act", F.silu(h))
     h = F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
     if (p + ".conv_shortcut.weight") in sd:
         x = F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])
