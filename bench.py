@@ -57,7 +57,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (1 = BASELINE configs[1], 64 = configs[2])")
-    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16"])
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "fp8"],
+                    help="operand dtype; fp8 = e4m3 MFMA path for the UNet's ResnetBlock2D 3x3 convs, f16 elsewhere (BASELINE configs[4])")
+    ap.add_argument("--vpred", action="store_true", help="v-prediction scheduler mode (the 768x768 SD-2.1 checkpoint of BASELINE configs[4])")
     ap.add_argument("--ddpm-steps", type=int, default=30)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-graph", action="store_true")
@@ -357,6 +359,11 @@ def main():
     from faceposegenerator_amd import spec as S, weights as W
 
     ucfg, vcfg = (S.TINY_UNET, S.TINY_VAE) if args.tiny else (S.SD21_UNET, S.SD21_VAE)
+    if args.vpred:
+        import dataclasses
+        ucfg = dataclasses.replace(ucfg, prediction_type="v_prediction")
+    if args.dtype == "fp8":
+        args.no_kernel_roofline = True          # the per-launch replay covers the 16-bit GEMM entry point only
     t0 = time.perf_counter()
     lora_raw = None
     if fake:
@@ -422,10 +429,14 @@ def main():
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if not fake else "FAKE pipeline on the CPU (launcher test, not a benchmark)",
-            "config": {"workload": ("BASELINE configs[1]" if B == 1 else "BASELINE configs[2]" if B == 64 else "custom") +
+            "config": {"workload": ("BASELINE configs[4], per-GPU share (batch 32 of 256 over 8 GPUs)" if (args.size == 768 and B == 32) else
+                                    "BASELINE configs[1]" if B == 1 else "BASELINE configs[2]" if B == 64 else "custom") +
                        f": SD-2.1-base graph{' (TINY, not a benchmark)' if args.tiny else ''} + rank-4 LoRA, {args.size}x{args.size}, "
                        f"{args.ddpm_steps} DDPM steps, CFG 5.0, batch {B}/GPU, synthetic weights",
                        "batch_per_gpu": B, "ddpm_steps": args.ddpm_steps, "guidance_scale": 5.0, "hip_graph": not args.no_graph,
+                       "prediction_type": "v_prediction" if args.vpred else "epsilon",
+                       **({"fp8_scope": "e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4) for the 44 ResnetBlock2D 3x3 convs = 40.6 % of the "
+                                        "UNet FLOPs; f16 operands elsewhere"} if args.dtype == "fp8" else {}),
                        "parallelism": f"identity-sharded x{world}, one all-gather of uint8 images per step" if world > 1 else "single GPU"},
         }
         if not fake:
