@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--vae-chunk", type=int, default=4)
     ap.add_argument("--no-config2", action="store_true", help="skip the short batch-64 (BASELINE configs[2]) timing of the default run")
+    ap.add_argument("--no-fp8-point", action="store_true", help="skip the batch-64 timing of the fp8 (e4m3 resnet convs) engine in the default run")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0, help="0 = all cores of the host (default); e.g. 8 for the build container's figure")
     return ap.parse_args()
 
@@ -420,6 +421,27 @@ def main():
                    "steps": 2, "warmup": 1, "ms_per_step": round(e64 / 2 * 1e3, 1), "tflops": round(tf64, 1),
                    "frac_of_mfma_peak": round(tf64 / PEAK_MFMA_TFLOPS, 4), "arena_mib": round(eng.arena.total_bytes / 2 ** 20, 1)}
 
+    fp8_point = None
+    if default_workload and world == 1 and not args.no_config2 and not args.no_fp8_point and args.dtype == "f16":
+        # the same batch-64 point on the fp8 path (BASELINE configs[4]'s "fp8 MFMA weight path", here at 512x512 so that it sits beside
+        # config2): a second engine with e4m3 resnet convs; its parity class is stated in DESIGN.md section 2.3 (opt-in, not the default)
+        del step64
+        pipe8 = StableDiffusionPipeline.from_synthetic(ucfg, vcfg, seed=1234, torch_dtype="fp8").to(dev)
+        pipe8.load_lora_weights(lora_raw)
+        pipe8.use_graph, pipe8.vae_chunk = pipe.use_graph, pipe.vae_chunk
+        keep, pipe = pipe, pipe8
+        step8, _ = make_step(64)
+        step8()
+        e8, g8, _ = time_steps(step8, 2, 1, dist, False)
+        pipe = keep
+        tf8 = 64 * 2 * flops_per_image / (g8 * 1e-3) / 1e12
+        fp8_point = {"workload": "batch 64/GPU, 512x512, 30 steps, LoRA; e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4 for the 44 ResnetBlock2D "
+                                 "3x3 convs, f16 elsewhere (python bench.py --batch 64 --dtype fp8)",
+                     "images_per_s": round(64 * 2 / e8, 3), "steps": 2, "warmup": 1, "ms_per_step": round(e8 / 2 * 1e3, 1),
+                     "algorithmic_tflops": round(tf8, 1), "parity": "eps rel-RMS 5.1e-2 vs the fp32 oracle per CFG forward (stated tolerance 7.7e-2)"}
+        del pipe8, step8
+        torch.cuda.empty_cache()
+
     if rank == 0:
         images = world * B * args.steps
         value = images / elapsed
@@ -447,6 +469,8 @@ def main():
                 res["path"]["stages"] = stage_times(pipe, eng, pe_d, ne_d, noise, args)
             if config2:
                 res["path"]["config2"] = config2
+            if fp8_point:
+                res["path"]["config2_fp8"] = fp8_point
             if not args.no_kernel_roofline:
                 res["roofline"], dom = kernel_roofline(eng, B, lat_side, 77)
                 attach_profile_evidence(res["roofline"], dom, B, args)

@@ -19,8 +19,8 @@ IDB_MAX_SRC = 4
 # every symbol include/idb_kernels.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "idb_version", "idb_launch_count", "idb_last_error", "idb_device_check",
-    "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm",
-    "idb_pack_conv_weight", "idb_pack_matrix", "idb_lora_merge",
+    "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm_row_stats_tiles", "idb_gemm",
+    "idb_pack_conv_weight", "idb_pack_matrix", "idb_lora_merge", "idb_lora_merge_scaled",
     "idb_groupnorm_workspace_bytes", "idb_groupnorm", "idb_layernorm", "idb_groupnorm_stats",
     "idb_hconv_workspace_bytes", "idb_hconv_plan", "idb_hconv",
     "idb_attention", "idb_embed_tokens", "idb_softmax_rows",
@@ -46,7 +46,8 @@ class GemmDesc(C.Structure):
                 ("out", C.c_void_p), ("out_dtype", C.c_int32), ("out_ld", C.c_int32),
                 ("split_k", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float), ("flags", C.c_int32), ("act", C.c_int32),
                 ("counters", C.c_void_p), ("counters_len", C.c_int32), ("gn_partials", C.c_void_p), ("gn_groups", C.c_int32),
-                ("pad_mode", C.c_int32)]
+                ("row_stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_tiles", C.c_int32), ("ln_u", C.c_void_p),
+                ("ln_v", C.c_void_p), ("ln_eps", C.c_float), ("pad_mode", C.c_int32)]
 
 
 class HconvSeg(C.Structure):
@@ -96,6 +97,8 @@ def load() -> C.CDLL:
         "idb_gemm_workspace_bytes": (sz, [C.POINTER(GemmDesc)]),
         "idb_gemm_plan": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "idb_gemm": (C.c_int, [C.POINTER(GemmDesc), vp, sz, vp]),
+        "idb_gemm_row_stats_tiles": (i32, [C.POINTER(GemmDesc)]),
+        "idb_lora_merge_scaled": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, i32, vp]),
         "idb_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
         "idb_pack_matrix": (C.c_int, [vp, vp, i64, i64, i32, i32, vp]),
         "idb_lora_merge": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, i32, vp]),

@@ -861,6 +861,19 @@ extern "C" size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d) {
     return pl.splitk > 1 ? (size_t)pl.splitk * pl.M * d->n * sizeof(float) : 0;
 }
 
+// the LDS-staged coalesced epilogue runs for this (descriptor, plan): the only epilogue that emits row statistics / folds a LayerNorm
+static bool gemm_uses_lds_epilogue(const idb_gemm_desc* d, const Plan& pl) {
+    const int no = d->geglu ? d->n / 2 : d->n;
+    return pl.tile / 10 != 4 && pl.tile / 10 != 3 && d->out_dtype == d->dtype && pl.splitk == 1 && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&
+           (!d->residual || idb_aligned16(d->residual));
+}
+
+extern "C" int32_t idb_gemm_row_stats_tiles(const idb_gemm_desc* d) {
+    Plan pl;
+    if (plan_gemm(d, &pl) != IDB_OK || !gemm_uses_lds_epilogue(d, pl)) return 0;
+    return pl.tiles_n;
+}
+
 extern "C" int idb_gemm_plan(const idb_gemm_desc* d, int32_t* tile, int32_t* split_k, int32_t* blocks) {
     Plan pl;
     int rc = plan_gemm(d, &pl);
@@ -938,6 +951,23 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
         p.lds_epi = (pl.tile / 10 != 4 && !p.out_f32 && (pl.splitk == 1 || fused_reduce) && no % 8 == 0 && d->out_ld % 8 == 0 && !(d->flags & 4) &&
                      (!d->residual || idb_aligned16(d->residual))) ? 1 : 0;
     }
+    if (d->row_stats_out || d->ln_stats) {
+        if (!p.lds_epi) {
+            idb_set_error("idb_gemm: row_stats_out / ln_stats need a plan with the LDS-staged epilogue (no split-K, no persistent / register-staged variant)");
+            return IDB_EUNSUPPORTED;
+        }
+        IDB_REQUIRE(!d->ln_stats || (d->ln_tiles > 0 && d->ln_u && d->ln_v && idb_aligned16(d->ln_u) && idb_aligned16(d->ln_v) && ((uintptr_t)d->ln_stats & 7) == 0 &&
+                                     d->nsrc == 1 && d->src[0].taps == 1 && d->n % 4 == 0),
+                    "idb_gemm: ln_stats needs ln_tiles > 0, aligned ln_u / ln_v, one 1x1 source, n %% 4 == 0");
+        IDB_REQUIRE(!d->row_stats_out || (((uintptr_t)d->row_stats_out & 7) == 0 && !d->geglu), "idb_gemm: row_stats_out must be 8-byte aligned, no GEGLU");
+    }
+    p.rowstat_out = d->row_stats_out;
+    p.ln_stats = d->ln_stats;
+    p.ln_u = d->ln_u;
+    p.ln_v = d->ln_v;
+    p.ln_nt = d->ln_tiles;
+    p.ln_c = (int)pl.K;
+    p.ln_eps = d->ln_eps;
     p.slab_swc = 0;
     if (d->gn_partials && pl.splitk > 1 && !p.counters && !(d->flags & 1) && !p.out_f32 && pl.M % 64 == 0) {
         // the reduce launch will be idb_splitk_reduce_gn_kernel: same conditions and slice width as launch_all computes

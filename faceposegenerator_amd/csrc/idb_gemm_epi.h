@@ -30,6 +30,14 @@ struct GemmParams {
     int dbg_skip_store, lds_epi, act, dbg_loop;   // dbg_* are read only by the profiling build (IDB_PROFILING, `make prof`)
     unsigned* counters;   // non-null: in-kernel split-K reduce
     unsigned out_bytes;   // persistent variant: size of the output tensor (buffer range check drops masked stores)
+    // LayerNorm folded into this GEMM (idb_gemm_desc.ln_*): A holds the RAW rows x, W its gamma-scaled weights; the LDS-staged
+    // epilogue turns acc = x W'^T into rstd (acc - mean u) + v from the per-row partial sums the producer of x emitted
+    float* rowstat_out;   // producer side: [M][tiles_n][2] partial {sum, sum of squares} of the rounded output rows
+    const float* ln_stats;
+    const float* ln_u;
+    const float* ln_v;
+    int ln_nt, ln_c;
+    float ln_eps;
 };
 
 // voffset of a lane that must read zeros: beyond num_records of every descriptor (all < 2^31), and
@@ -64,6 +72,24 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
     const int No = GEGLU ? p.N / 2 : p.N;
     const int n0o = GEGLU ? n0 / 2 : n0;
     __syncthreads();                                   // every wave is done reading the last K tile
+    float2* rowtab = (float2*)(smem + ((BM * OLD + 15) & ~15));          // behind the staging area: {mean, rstd} per tile row
+    if (p.ln_stats) {
+        if (tid < BM) {
+            const int m = min(m0 + tid, p.M - 1);
+            const float* ps = p.ln_stats + (long long)m * p.ln_nt * 2;
+            double a = 0.0, q = 0.0;
+            for (int t = 0; t < p.ln_nt; ++t) {
+                const float2 v = *(const float2*)(ps + 2 * t);
+                a += (double)v.x;
+                q += (double)v.y;
+            }
+            const double mean = a / p.ln_c;
+            double var = q / p.ln_c - mean * mean;
+            if (var < 0.0) var = 0.0;
+            rowtab[tid] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.ln_eps)));
+        }
+        if (!p.res) __syncthreads();                   // with a residual the barrier below publishes the table as well
+    }
     if (p.res) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
@@ -86,9 +112,14 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
                 const int nv = n0 + (wn * NF + j) * 16 + fg * 4;
                 const int col = (wn * NF + j) * 8 + fg * 4;
                 float o[4];
+                const float2 mr = p.ln_stats ? rowtab[row] : make_float2(0.f, 1.f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[i][j][e] * p.scale, gt = acc[i][j + 1][e] * p.scale;
+                    if (p.ln_stats && nv + 16 < p.N) {
+                        v = mr.y * (v - mr.x * p.ln_u[nv + e]) + p.ln_v[nv + e];
+                        gt = mr.y * (gt - mr.x * p.ln_u[nv + 16 + e]) + p.ln_v[nv + 16 + e];
+                    }
                     if (p.bias && nv + 16 < p.N) {
                         v += p.bias[nv + e];
                         gt += p.bias[nv + 16 + e];
@@ -107,6 +138,12 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
                 if (n < p.N) {
+                    if (p.ln_stats) {
+                        const float2 mr = rowtab[row];
+                        const f32x4 u4 = *(const f32x4*)(p.ln_u + n), v4 = *(const f32x4*)(p.ln_v + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = mr.y * (o[e] - mr.x * u4[e]) + v4[e];
+                    }
                     if (p.bias) {
                         const f32x4 b4 = *(const f32x4*)(p.bias + n);
 #pragma unroll
@@ -133,6 +170,24 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
         }
     }
     __syncthreads();
+    if (p.rowstat_out && tid < BM && m0 + tid < p.M) {
+        // per-row partial {sum, sum of squares} of the ROUNDED tile row (what a LayerNorm of the output would read), one entry per
+        // column tile: the consumer GEMM (idb_gemm_desc.ln_stats) adds the tiles_n entries of a row
+        const char* rp = smem + tid * OLD;
+        float a = 0.f, q = 0.f;
+        for (int c = 0; c < CPR; ++c) {
+            if (n0o + c * 8 < No) {
+                const V8 v = *(const V8*)(rp + c * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = to_f32<T>(v[e]);
+                    a += f;
+                    q += f * f;
+                }
+            }
+        }
+        *(float2*)(p.rowstat_out + ((long long)(m0 + tid) * p.tiles_n + n0 / BN) * 2) = make_float2(a, q);
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int q = it * THREADS + tid;

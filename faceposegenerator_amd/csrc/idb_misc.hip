@@ -303,6 +303,18 @@ __global__ __launch_bounds__(256) void lora_merge_kernel(const float* __restrict
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void lora_merge_scaled_kernel(const float* __restrict__ w, const float* __restrict__ a,
+                                                                const float* __restrict__ bm, T* __restrict__ dst, long long rows,
+                                                                long long cols, int rank, float scale, const float* __restrict__ cs) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long long r = i / cols, c = i - r * cols;
+    float d = 0.f;
+    for (int k = 0; k < rank; ++k) d += bm[r * rank + k] * a[(long long)k * cols + c];
+    dst[i] = from_f32<T>((w[i] + scale * d) * cs[c]);
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ ids, const float* __restrict__ tok,
                                                     const float* __restrict__ pos, T* __restrict__ out, int rows, int n_tokens, int dim) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per 4 output features
@@ -462,6 +474,19 @@ extern "C" int idb_pack_matrix(const float* src, void* dst, int64_t rows, int64_
     DISPATCH_T(dtype, hipLaunchKernelGGL((pack_matrix_kernel<__bf16>), dim3(nb), dim3(256), 0, st, src, (__bf16*)dst, (long long)rows, (long long)cols, geglu),
                hipLaunchKernelGGL((pack_matrix_kernel<_Float16>), dim3(nb), dim3(256), 0, st, src, (_Float16*)dst, (long long)rows, (long long)cols, geglu));
     IDB_CHECK_LAUNCH("idb_pack_matrix");
+    return IDB_OK;
+}
+
+extern "C" int idb_lora_merge_scaled(const float* w, const float* lora_a, const float* lora_b, void* dst, int64_t rows, int64_t cols,
+                                     int32_t rank, float scale, const float* col_scale, int32_t dtype, void* stream) {
+    IDB_REQUIRE(idb_is_operand_dtype(dtype) && w && dst && col_scale && rows > 0 && cols > 0 && rank >= 0 && ((lora_a && lora_b) || rank == 0),
+                "idb_lora_merge_scaled: bad args");
+    const unsigned nb = blocks_for(rows * cols);
+    hipStream_t st = (hipStream_t)stream;
+    const int rk = lora_a ? rank : 0;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((lora_merge_scaled_kernel<__bf16>), dim3(nb), dim3(256), 0, st, w, lora_a, lora_b, (__bf16*)dst, (long long)rows, (long long)cols, rk, scale, col_scale),
+               hipLaunchKernelGGL((lora_merge_scaled_kernel<_Float16>), dim3(nb), dim3(256), 0, st, w, lora_a, lora_b, (_Float16*)dst, (long long)rows, (long long)cols, rk, scale, col_scale));
+    IDB_CHECK_LAUNCH("idb_lora_merge_scaled");
     return IDB_OK;
 }
 

@@ -124,6 +124,9 @@ class HipEngine:
         # DESIGN.md section 5): 47 us against 31 + 9.6 us for idb_gemm + the gn_apply launch on the 320->320 @64x64 layer, 5.70
         # against 6.62 images/s end to end — the in-LDS SiLU costs more than the launch it saves, so the policy default is OFF and
         # IDB_HCONV=1 turns it on (grids of at most IDB_HCONV_TILES 128-row tiles: the kernel holds one workgroup per CU).
+        # LayerNorm folded into the consuming projection (to_q/k/v, attn2.to_q, GEGLU-in): row statistics from the producer's epilogue,
+        # rstd / mean correction in the consumer's; IDB_LN_FOLD=0 keeps the idb_layernorm launches
+        self._ln_fold = os.environ.get("IDB_LN_FOLD", "1") != "0"
         self._use_hconv = os.environ.get("IDB_HCONV", "0") == "1"
         self._hconv_tiles = int(os.environ.get("IDB_HCONV_TILES", "512"))
         self._hconv_proj_in = os.environ.get("IDB_HCONV_PROJ_IN", "1") != "0"      # Transformer2DModel.norm + proj_in fused as well
@@ -250,6 +253,20 @@ class HipEngine:
             w[f"{n}.o2.b"] = self._f32(sd[f"{b}.attn2.to_out.0.bias"])
             w[f"{n}.ff1.w"] = self._pack_mat(sd[f"{b}.ff.net.0.proj.weight"], geglu=True)
             w[f"{n}.ff1.b"] = self._f32(sd[f"{b}.ff.net.0.proj.bias"][self._geglu_perm(8 * c)])
+            # folded-LayerNorm operands (idb_gemm_desc.ln_*): W' = W * gamma along K (one rounding), u = row sums of the ROUNDED W',
+            # v = W beta in fp32; the LoRA-affected ones (qkv, q2) are (re)built by set_lora
+            perm = self._geglu_perm(8 * c).to(self.device)
+            wf = self._f32(sd[f"{b}.ff.net.0.proj.weight"])
+            w[f"{n}.ff1.wln"] = self._pack_mat(wf * w[f"{n}.ln3.g"][None, :], geglu=True)
+            w[f"{n}.ff1.u"] = w[f"{n}.ff1.wln"].float().sum(dim=1).contiguous()
+            w[f"{n}.ff1.v"] = (wf @ w[f"{n}.ln3.b"])[perm].contiguous()
+            del wf
+            w[f"{n}.qkv.wln"] = torch.empty((3 * c, c), dtype=self.tdt, device=self.device)
+            w[f"{n}.q2.wln"] = torch.empty((c, c), dtype=self.tdt, device=self.device)
+            w[f"{n}.qkv.v"] = torch.empty((3 * c,), dtype=torch.float32, device=self.device)
+            w[f"{n}.q2.v"] = torch.empty((c,), dtype=torch.float32, device=self.device)
+            w[f"{n}.qkv.u"] = torch.empty((3 * c,), dtype=torch.float32, device=self.device)     # filled IN PLACE by set_lora: captured
+            w[f"{n}.q2.u"] = torch.empty((c,), dtype=torch.float32, device=self.device)          # graphs hold these addresses
             w[f"{n}.ff2.w"] = self._pack_mat(sd[f"{b}.ff.net.2.weight"])
             w[f"{n}.ff2.b"] = self._f32(sd[f"{b}.ff.net.2.bias"])
         w["conv_norm_out.g"] = self._f32(sd["conv_norm_out.weight"])
@@ -289,9 +306,20 @@ class HipEngine:
                     dst_ptr = mat.data_ptr() + row0 * mat.shape[1] * 2
                     assert mat.shape[1] == cols
                     la = None if lora is None else lora.get(key + ".lora_A.weight")
+                    # folded-LayerNorm copy of the projections that read a LayerNorm output: attn1 to_q/k/v (norm1), attn2 to_q (norm2)
+                    fold = None
+                    if attn == "attn1" and t != "to_out.0":
+                        fold = (self.w[f"{a.name}.qkv.wln"], self.w[f"{a.name}.qkv.v"], row0, self.w[f"{a.name}.ln1.g"], self.w[f"{a.name}.ln1.b"])
+                    elif attn == "attn2" and t == "to_q":
+                        fold = (self.w[f"{a.name}.q2.wln"], self.w[f"{a.name}.q2.v"], 0, self.w[f"{a.name}.ln2.g"], self.w[f"{a.name}.ln2.b"])
                     if la is None:
                         L.check(self.lib.idb_pack_matrix(master.data_ptr(), dst_ptr, rows, cols, 0, self.dt, _stream()),
                                 "idb_pack_matrix")
+                        if fold is not None:
+                            fmat, fv, fr0, gam, bet = fold
+                            L.check(self.lib.idb_lora_merge_scaled(master.data_ptr(), None, None, fmat.data_ptr() + fr0 * cols * 2, rows, cols, 0, 0.0,
+                                                                   gam.data_ptr(), self.dt, _stream()), "idb_lora_merge_scaled")
+                            fv[fr0:fr0 + rows] = master @ bet
                         continue
                     lb = lora[key + ".lora_B.weight"]
                     rank = la.shape[0]
@@ -302,7 +330,16 @@ class HipEngine:
                     la_d, lb_d = self._f32(la), self._f32(lb)
                     L.check(self.lib.idb_lora_merge(master.data_ptr(), la_d.data_ptr(), lb_d.data_ptr(), dst_ptr, rows, cols,
                                                     rank, float(scale * alpha / rank), self.dt, _stream()), "idb_lora_merge")
+                    if fold is not None:
+                        fmat, fv, fr0, gam, bet = fold
+                        sc = float(scale * alpha / rank)
+                        L.check(self.lib.idb_lora_merge_scaled(master.data_ptr(), la_d.data_ptr(), lb_d.data_ptr(), fmat.data_ptr() + fr0 * cols * 2,
+                                                               rows, cols, rank, sc, gam.data_ptr(), self.dt, _stream()), "idb_lora_merge_scaled")
+                        fv[fr0:fr0 + rows] = master @ bet + sc * (lb_d @ (la_d @ bet))
                     used += 1
+        for a in self._attn_specs:                       # u = row sums of the rounded folded operands (what the MFMA multiplies)
+            self.w[f"{a.name}.qkv.u"].copy_(self.w[f"{a.name}.qkv.wln"].float().sum(dim=1))
+            self.w[f"{a.name}.q2.u"].copy_(self.w[f"{a.name}.q2.wln"].float().sum(dim=1))
         if lora is not None:
             n_pairs = sum(1 for k in lora if k.endswith(".lora_A.weight"))
             if used != n_pairs:
@@ -380,10 +417,13 @@ class HipEngine:
     def gemm(self, srcs, w: torch.Tensor, n: int, batch: int, oh: int, ow: int, bias=None, sbias=None,
              residual=None, geglu=False, stride=1, out_f32=False, out_scale=0.0, split_k=0, tile=0,
              out: Optional[torch.Tensor] = None, flags: int = 0, act: int = 0, pad_mode: int = 0, gn_stats: int = 0,
-             gn_stats_always: bool = False) -> torch.Tensor:
-        """srcs: list of (tensor, channels, taps, in_h, in_w, upsample); sbias: (tensor, elem_offset, ld)."""
+             gn_stats_always: bool = False, row_stats: bool = False, ln=None) -> torch.Tensor:
+        """srcs: list of (tensor, channels, taps, in_h, in_w, upsample); sbias: (tensor, elem_offset, ld).
+        row_stats: also emit the per-row partial sums a folded LayerNorm of the output needs (``out._rs = (buffer, tiles)``) when the
+        plan can; ln = (stats, tiles, u, v, eps): A holds raw rows, w the gamma-scaled weights (idb_gemm_desc.ln_*)."""
         m = batch * oh * ow
         ncols = n // 2 if geglu else n
+        own_out = out is None
         if out is None:
             out = self.arena.alloc((m, ncols), torch.float32 if out_f32 else self.tdt)
         d = L.GemmDesc()
@@ -399,6 +439,20 @@ class HipEngine:
         d.out, d.out_dtype, d.out_ld = out.data_ptr(), (L.IDB_F32 if out_f32 else self.dt), out.shape[-1]
         d.split_k, d.tile, d.out_scale, d.flags, d.act = split_k, tile, out_scale, flags, act
         d.pad_mode = pad_mode
+        rs_buf = None
+        if row_stats and self._ln_fold:
+            nt = self.lib.idb_gemm_row_stats_tiles(C.byref(d))
+            if nt > 0:
+                rs_buf = self.arena.alloc((m * nt * 2,), torch.float32)
+                d.row_stats_out = rs_buf.data_ptr()
+        if ln is not None:
+            if self.lib.idb_gemm_row_stats_tiles(C.byref(d)) == 0:      # this plan cannot fold (split-K / persistent): caller keeps idb_layernorm
+                if own_out:
+                    self.arena.free(out)
+                if rs_buf is not None:
+                    self.arena.free(rs_buf)
+                return None
+            d.ln_stats, d.ln_tiles, d.ln_u, d.ln_v, d.ln_eps = ln[0].data_ptr(), ln[1], ln[2].data_ptr(), ln[3].data_ptr(), ln[4]
         gn_part = None
         if gn_stats and self._gn_fuse and (oh * ow) % 64 == 0 and oh * ow <= 4096 and not geglu and not out_f32 and n % gn_stats == 0:
             # the GroupNorm that consumes `out` next gets its first pass from this GEMM's split-K reduce launch (idb_kernels.h);
@@ -421,6 +475,8 @@ class HipEngine:
         L.check(self.lib.idb_gemm(C.byref(d), _ptr(ws), need, _stream()), "idb_gemm")
         if gn_part is not None:
             out._gn = (gn_part, oh * ow // 64, gn_stats)
+        if rs_buf is not None:
+            out._rs = (rs_buf, nt)
         if log is not None:
             ev1.record()
             log.append({"tile": tile.value, "split_k": sk.value, "blocks": blocks.value, "m": m, "n": n, "k": k_total,
@@ -594,6 +650,26 @@ class HipEngine:
                                        self.dt, _stream()), "idb_layernorm")
         return out
 
+    def ln_linear(self, x, rows, c, pfx: str, ln_name: str, wname: str, n: int, **kw) -> torch.Tensor:
+        """LayerNorm(x) @ W^T: folded into ONE GEMM when x carries row statistics (``_rs``) and the consumer's plan runs the LDS-staged
+        epilogue; else idb_layernorm + the plain GEMM.  Weights: ``{pfx}.{wname}.w`` (plain), ``.wln`` / ``.u`` / ``.v`` (folded)."""
+        W = self.w
+        rs = getattr(x, "_rs", None)
+        if rs is not None and self._ln_fold:
+            out = self.linear(x, W[f"{pfx}.{wname}.wln"], n, c, ln=(rs[0], rs[1], W[f"{pfx}.{wname}.u"], W[f"{pfx}.{wname}.v"], 1e-5), **kw)
+            if out is not None:
+                return out
+        t = self.layernorm(x, rows, c, W[f"{pfx}.{ln_name}.g"], W[f"{pfx}.{ln_name}.b"])
+        out = self.linear(t, W[f"{pfx}.{wname}.w"], n, c, **kw)
+        self.arena.free(t)
+        return out
+
+    def _free_rs(self, x) -> None:
+        rs = getattr(x, "_rs", None)
+        if rs is not None:
+            x._rs = None
+            self.arena.free(rs[0])
+
     def attention(self, q, q_ld, k_ptr, v_ptr, kv_ld, batch, heads, n_q, n_kv, n_kv_alloc, causal: bool = False) -> torch.Tensor:
         out = self.arena.alloc((batch * n_q, heads * 64), self.tdt)
         L.check(self.lib.idb_attention(q.data_ptr(), q_ld, k_ptr, v_ptr, kv_ld, out.data_ptr(), heads * 64, batch, heads,
@@ -688,32 +764,29 @@ class HipEngine:
             self.arena.free(part)
         else:
             xn = self.groupnorm(x, c, None, 0, batch, hw, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
-            h0 = self.linear(xn, W[f"{n}.proj_in.w"], c, c, bias=W[f"{n}.proj_in.b"])
+            h0 = self.linear(xn, W[f"{n}.proj_in.w"], c, c, bias=W[f"{n}.proj_in.b"], row_stats=True)
             self.arena.free(xn)
         # self-attention
-        t = self.layernorm(h0, m, c, W[f"{n}.ln1.g"], W[f"{n}.ln1.b"])
-        qkv = self.linear(t, W[f"{n}.qkv.w"], 3 * c, c)
-        self.arena.free(t)
+        qkv = self.ln_linear(h0, m, c, n, "ln1", "qkv", 3 * c)
+        self._free_rs(h0)
         p = qkv.data_ptr()
         o = self.attention(qkv, 3 * c, p + 2 * c, p + 4 * c, 3 * c, batch, a.heads, hw, hw, hw)
         self.arena.free(qkv)
-        h1 = self.linear(o, W[f"{n}.o1.w"], c, c, bias=W[f"{n}.o1.b"], residual=h0)
+        h1 = self.linear(o, W[f"{n}.o1.w"], c, c, bias=W[f"{n}.o1.b"], residual=h0, row_stats=True)
         self.arena.free(o)
         self.arena.free(h0)
         # cross-attention (K/V of the prompt embeddings are per-call constants)
-        t = self.layernorm(h1, m, c, W[f"{n}.ln2.g"], W[f"{n}.ln2.b"])
-        q2 = self.linear(t, W[f"{n}.q2.w"], c, c)
-        self.arena.free(t)
+        q2 = self.ln_linear(h1, m, c, n, "ln2", "q2", c)
+        self._free_rs(h1)
         kp = kv.data_ptr()
         o = self.attention(q2, c, kp, kp + 2 * c, 2 * c, batch, a.heads, hw, n_ctx, n_ctx)
         self.arena.free(q2)
-        h2 = self.linear(o, W[f"{n}.o2.w"], c, c, bias=W[f"{n}.o2.b"], residual=h1)
+        h2 = self.linear(o, W[f"{n}.o2.w"], c, c, bias=W[f"{n}.o2.b"], residual=h1, row_stats=True)
         self.arena.free(o)
         self.arena.free(h1)
         # GEGLU feed-forward
-        t = self.layernorm(h2, m, c, W[f"{n}.ln3.g"], W[f"{n}.ln3.b"])
-        gg = self.linear(t, W[f"{n}.ff1.w"], 8 * c, c, bias=W[f"{n}.ff1.b"], geglu=True)
-        self.arena.free(t)
+        gg = self.ln_linear(h2, m, c, n, "ln3", "ff1", 8 * c, bias=W[f"{n}.ff1.b"], geglu=True)
+        self._free_rs(h2)
         h3 = self.linear(gg, W[f"{n}.ff2.w"], c, 4 * c, bias=W[f"{n}.ff2.b"], residual=h2)
         self.arena.free(gg)
         self.arena.free(h2)

@@ -97,6 +97,19 @@ typedef struct {
                                  statistics launch otherwise.  Needs out_h*out_w % 64 == 0, out_h*out_w <= 4096, n % gn_groups == 0,
                                  operand-dtype output, no GEGLU */
     int32_t gn_groups;
+    /* LayerNorm folded into the GEMM (BasicTransformerBlock norm1/2/3 -> to_q/k/v, attn2.to_q, ff.net.0): `src` holds the RAW rows
+     * x [M][K = ln_c]; `w` = W scaled by the LayerNorm gamma along K; out = rstd_m (x W'^T - mean_m u) + v (+ bias ...), with
+     * u[n] = sum_k W'[n][k] (of the ROUNDED operand values) and v[n] = sum_k beta[k] W[n][k] (fp32 [n], 16-byte aligned), and the
+     * per-row statistics taken from ln_stats = the row_stats_out of the GEMM that produced x: fp32 [M][ln_tiles][2] partial
+     * {sum, sum of squares} per column tile.  Exact in fp32 (x W'^T - mean u = (x - mean) W'^T term by term).  Only plans that
+     * run the LDS-staged epilogue support either side (no split-K, no persistent variant, operand-dtype output): idb_gemm returns
+     * IDB_EUNSUPPORTED otherwise and the caller keeps idb_layernorm; idb_gemm_row_stats_tiles tells beforehand (0 = unsupported). */
+    float* row_stats_out;     /* optional out: [M][idb_gemm_row_stats_tiles(d)][2] */
+    const float* ln_stats;    /* optional in */
+    int32_t ln_tiles;
+    const float* ln_u;
+    const float* ln_v;
+    float ln_eps;
     int32_t pad_mode;         /* taps=9 sources — 0: zero padding 1 on every side (nn.Conv2d padding=1); 1: padding on the
                                  bottom/right only, i.e. F.pad(x, (0,1,0,1)) + padding=0, the stride-2 Downsample2D of the VAE
                                  encoder (diffusers downsampling.py; AutoencoderKL.encode at train_ID-Booth.py:1001) */
@@ -107,6 +120,9 @@ size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);
  * 4: 64x64 (8 waves), 5: 128x32, 6-9: 64x160 / 64x128 / 128x160 / 128x128 with 8 waves; variant 0/1: 2-/3-stage LDS ring,
  * 4: persistent), split-K factor and workgroup count.  Host-only, no GPU call. */
 int idb_gemm_plan(const idb_gemm_desc* d, int32_t* tile, int32_t* split_k, int32_t* blocks);
+/* Column tiles of the plan idb_gemm would run for `d` if that plan can emit row statistics / apply a folded LayerNorm (LDS-staged
+ * epilogue), else 0. */
+int32_t idb_gemm_row_stats_tiles(const idb_gemm_desc* d);
 int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight packing (run once at load; SURVEY.md §8b "idb_pack_*"). src is fp32 in torch layout. */
@@ -120,6 +136,10 @@ int idb_pack_matrix(const float* src, void* dst, int64_t rows, int64_t cols, int
  * (peft lora.Linear with merged weights; inference_ID-Booth.py:107). */
 int idb_lora_merge(const float* w, const float* lora_a, const float* lora_b, void* dst, int64_t rows,
                    int64_t cols, int32_t rank, float scale, int32_t dtype, void* stream);
+/* The same with every column k multiplied by col_scale[k] before the one rounding (the gamma of a folded LayerNorm);
+ * lora_a == NULL (rank 0): dst = round(W * col_scale). */
+int idb_lora_merge_scaled(const float* w, const float* lora_a, const float* lora_b, void* dst, int64_t rows, int64_t cols,
+                          int32_t rank, float scale, const float* col_scale, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1 (norm part) / K6 — GroupNorm and LayerNorm.
