@@ -189,6 +189,9 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st)
         if (st < nk) stage(st);
+    // folded LayerNorm: this thread's share of its tile row's statistics, the loads in flight with the first operand tiles
+    float2 ln_part = make_float2(0.f, 0.f);
+    if (p.ln_stats) ln_part = idb_ln_row_partials<BM, THREADS>(p, m0, tid);
     int cur = 0;
     for (int it = 0; it < nk; ++it) {
         if (NS > 2 && it + NS - 2 < nk)
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
 
-    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, kz);
+    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, kz, p.ln_stats != nullptr, ln_part);
 #endif
 }
 
@@ -952,13 +955,14 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
                      (!d->residual || idb_aligned16(d->residual))) ? 1 : 0;
     }
     if (d->row_stats_out || d->ln_stats) {
-        if (!p.lds_epi) {
+        if (!p.lds_epi || pl.tile / 10 == 3) {
             idb_set_error("idb_gemm: row_stats_out / ln_stats need a plan with the LDS-staged epilogue (no split-K, no persistent / register-staged variant)");
             return IDB_EUNSUPPORTED;
         }
         IDB_REQUIRE(!d->ln_stats || (d->ln_tiles > 0 && d->ln_u && d->ln_v && idb_aligned16(d->ln_u) && idb_aligned16(d->ln_v) && ((uintptr_t)d->ln_stats & 7) == 0 &&
-                                     d->nsrc == 1 && d->src[0].taps == 1 && d->n % 4 == 0),
-                    "idb_gemm: ln_stats needs ln_tiles > 0, aligned ln_u / ln_v, one 1x1 source, n %% 4 == 0");
+                                     d->nsrc == 1 && d->src[0].taps == 1 && d->n % 4 == 0 && !d->bias && !d->sample_bias),
+                    "idb_gemm: ln_stats needs ln_tiles > 0, aligned ln_u / ln_v, one 1x1 source, n %% 4 == 0, and no bias / sample_bias "
+                    "(add the layer's bias into ln_v)");
         IDB_REQUIRE(!d->row_stats_out || (((uintptr_t)d->row_stats_out & 7) == 0 && !d->geglu), "idb_gemm: row_stats_out must be 8-byte aligned, no GEGLU");
     }
     p.rowstat_out = d->row_stats_out;

@@ -59,9 +59,56 @@ struct GemmParams {
 //   phase R (residual only): coalesced copy of the residual tile into LDS
 //   phase W: each lane adds bias / per-sample bias / residual (fp32, ONE rounding) and writes its 4-channel pieces in place
 //   phase S: coalesced LDS -> global stores
+// Folded LayerNorm (GemmParams::ln_stats), part 1 — called from the kernel PROLOGUE behind the first LDS-DMA issues: THREADS / BM
+// threads per tile row add their share of the row's ln_nt partial {sum, sum of squares}; the loads travel with the first operand
+// tiles instead of standing exposed in every tile's epilogue (measured +33 % on the GEGLU projections there).  The two partial
+// sums ride through the K loop in registers: a table in LDS beside the ring was measured to cost the 128x160 2-stage tile its
+// second workgroup per CU (+37-51 % on the QKV projections).
+template <int BM, int THREADS>
+__device__ __forceinline__ float2 idb_ln_row_partials(const GemmParams& p, int m0, int tid) {
+    constexpr int TPR = THREADS / BM;
+    const int row = tid / TPR, sub = tid % TPR;
+    const int m = min(m0 + row, p.M - 1);
+    const float* ps = p.ln_stats + (long long)m * p.ln_nt * 2;
+    float a = 0.f, q = 0.f;
+    for (int t0 = 0; t0 < p.ln_nt; t0 += 4 * TPR) {
+        float2 pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv[k] = *(const float2*)(ps + 2 * min(t0 + sub + k * TPR, p.ln_nt - 1));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in = t0 + sub + k * TPR < p.ln_nt;
+            a += in ? pv[k].x : 0.f;
+            q += in ? pv[k].y : 0.f;
+        }
+    }
+    return make_float2(a, q);
+}
+
+// Part 2 — at the head of the epilogue: shuffle tree over the row's threads, {mean, rstd} into `rowtab` (LDS, BM entries, in the
+// ring the K loop is done with); the caller's barrier publishes it.
+template <int BM, int THREADS>
+__device__ __forceinline__ void idb_ln_row_table(const GemmParams& p, float2* rowtab, int tid, float2 part) {
+    constexpr int TPR = THREADS / BM;
+    float a = part.x, q = part.y;
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if (tid % TPR == 0) {
+        const float inv_c = 1.0f / (float)p.ln_c;
+        const float mean = a * inv_c;
+        // E[x^2] - mean^2 in double: the two terms can agree to 4-5 digits when |mean| >> std
+        double var = (double)q * (double)inv_c - (double)mean * (double)mean;
+        if (var < 0.0) var = 0.0;
+        rowtab[tid / TPR] = make_float2(mean, __builtin_amdgcn_rsqf((float)var + p.ln_eps));
+    }
+}
+
 template <typename T, int MF, int NF, bool GEGLU, int WM = 2>
 __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
-                                                 int wm, int wn, int fr, int fg) {
+                                                 int wm, int wn, int fr, int fg, bool ln = false, float2 ln_part = {0.f, 0.f}) {
     using V8 = typename Op<T>::v8;
     using V4 = typename Op<T>::v4;
     constexpr int BM = 16 * MF * WM, BN = 32 * NF, THREADS = 128 * WM;
@@ -72,23 +119,11 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
     const int No = GEGLU ? p.N / 2 : p.N;
     const int n0o = GEGLU ? n0 / 2 : n0;
     __syncthreads();                                   // every wave is done reading the last K tile
-    float2* rowtab = (float2*)(smem + ((BM * OLD + 15) & ~15));          // behind the staging area: {mean, rstd} per tile row
-    if (p.ln_stats) {
-        if (tid < BM) {
-            const int m = min(m0 + tid, p.M - 1);
-            const float* ps = p.ln_stats + (long long)m * p.ln_nt * 2;
-            double a = 0.0, q = 0.0;
-            for (int t = 0; t < p.ln_nt; ++t) {
-                const float2 v = *(const float2*)(ps + 2 * t);
-                a += (double)v.x;
-                q += (double)v.y;
-            }
-            const double mean = a / p.ln_c;
-            double var = q / p.ln_c - mean * mean;
-            if (var < 0.0) var = 0.0;
-            rowtab[tid] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.ln_eps)));
-        }
-        if (!p.res) __syncthreads();                   // with a residual the barrier below publishes the table as well
+    float2* rowtab = nullptr;
+    if (ln) {                                          // folded LayerNorm: {mean, rstd} per tile row, behind the staging area
+        rowtab = (float2*)(smem + ((BM * OLD + 15) & ~15));
+        idb_ln_row_table<BM, THREADS>(p, rowtab, tid, ln_part);
+        if (!p.res) __syncthreads();
     }
     if (p.res) {
 #pragma unroll
@@ -101,28 +136,50 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
         }
         __syncthreads();
     }
+    // Column vectors of this lane's NF fragments, loaded ONCE before the row loop and unconditionally (an absent term reads a
+    // valid dummy address and is dropped by a value select): the loads are then independent and all in flight together.  Loads
+    // behind `if (p.bias)` / `if (sb)` inside the (i, j) loop were issued and awaited one by one — 2-4 exposed L2 round trips
+    // per fragment, measured +20-70 % on the K = C projections once the folded-LayerNorm vectors joined them.
+    // Two vectors per fragment (more in flight costs the 8-wave tiles their second workgroup per CU in VGPRs):
+    //   ca = bias, or ln_v of a folded LayerNorm (the caller adds the layer's bias into ln_v; idb_gemm rejects bias + ln_stats)
+    //   cb = the per-sample bias when the whole tile lies in one sample, or ln_u
+    const int m_last = min(m0 + BM, p.M) - 1;
+    const bool sb_tile = p.sbias && (m0 / p.HW == m_last / p.HW);      // else (HW < BM): per-row loads below
+    const float* dummy = (const float*)p.w;
+    const float* pa = rowtab ? p.ln_v : p.bias;
+    const float* pb = rowtab ? p.ln_u : (sb_tile ? p.sbias + (long long)(m0 / p.HW) * p.sbias_ld : nullptr);
+    f32x4 ca[NF], cb[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int nc = min(n0 + (wn * NF + j) * 16 + fg * 4, p.N - 4);
+        const f32x4 a4 = *(const f32x4*)(pa ? pa + nc : dummy);
+        const f32x4 b4 = *(const f32x4*)(pb ? pb + nc : dummy);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ca[j][e] = pa ? a4[e] : 0.f;
+            cb[j][e] = pb ? b4[e] : 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int row = (wm * MF + i) * 16 + fr;
         const int mc = min(m0 + row, p.M - 1);
-        const float* sb = p.sbias ? p.sbias + (long long)(mc / p.HW) * p.sbias_ld : nullptr;
+        const float* sb = (p.sbias && !sb_tile) ? p.sbias + (long long)(mc / p.HW) * p.sbias_ld : nullptr;
+        const float2 mr = rowtab ? rowtab[row] : make_float2(0.f, 1.f);
+        // folded LayerNorm: rstd (scale acc - mean u) + v = rs acc + kb u + v;  otherwise scale acc + bias + per-sample bias
+        const float rs = mr.y * p.scale, kb = rowtab ? -mr.x * mr.y : 1.f;
         if constexpr (GEGLU) {
 #pragma unroll
             for (int j = 0; j < NF; j += 2) {
                 const int nv = n0 + (wn * NF + j) * 16 + fg * 4;
                 const int col = (wn * NF + j) * 8 + fg * 4;
                 float o[4];
-                const float2 mr = p.ln_stats ? rowtab[row] : make_float2(0.f, 1.f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][j][e] * p.scale, gt = acc[i][j + 1][e] * p.scale;
-                    if (p.ln_stats && nv + 16 < p.N) {
-                        v = mr.y * (v - mr.x * p.ln_u[nv + e]) + p.ln_v[nv + e];
-                        gt = mr.y * (gt - mr.x * p.ln_u[nv + 16 + e]) + p.ln_v[nv + 16 + e];
-                    }
-                    if (p.bias && nv + 16 < p.N) {
-                        v += p.bias[nv + e];
-                        gt += p.bias[nv + 16 + e];
+                    float v = rs * acc[i][j][e], gt = rs * acc[i][j + 1][e];
+                    if (nv + 16 < p.N) {
+                        v += kb * cb[j][e] + ca[j][e];
+                        gt += kb * cb[j + 1][e] + ca[j + 1][e];
                     }
                     o[e] = v * gelu_erf_f(gt);
                 }
@@ -136,19 +193,10 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
                 const int n = n0 + col;
                 float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
+                for (int e = 0; e < 4; ++e) o[e] = rs * acc[i][j][e];
                 if (n < p.N) {
-                    if (p.ln_stats) {
-                        const float2 mr = rowtab[row];
-                        const f32x4 u4 = *(const f32x4*)(p.ln_u + n), v4 = *(const f32x4*)(p.ln_v + n);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = mr.y * (o[e] - mr.x * u4[e]) + v4[e];
-                    }
-                    if (p.bias) {
-                        const f32x4 b4 = *(const f32x4*)(p.bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += b4[e];
-                    }
+                    for (int e = 0; e < 4; ++e) o[e] += kb * cb[j][e] + ca[j][e];
                     if (sb) {
                         const f32x4 b4 = *(const f32x4*)(sb + n);
 #pragma unroll
@@ -170,12 +218,23 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
         }
     }
     __syncthreads();
-    if (p.rowstat_out && tid < BM && m0 + tid < p.M) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int q = it * THREADS + tid;
+        const int row = q / CPR, c = q - row * CPR;
+        const int m = m0 + row, n = n0o + c * 8;
+        const int mo = IDB_DBG(p.dbg_skip_store) == 2 ? (m & 127) : m;      // profiling: every tile writes the same L2-resident rows
+        if (q < NCHUNK && m < p.M && n < No) *(V8*)((T*)p.out + (long long)mo * p.out_ld + n) = *(const V8*)(smem + row * OLD + c * 16);
+    }
+    if (p.rowstat_out) {                                   // behind the stores: its LDS reads overlap their flight
         // per-row partial {sum, sum of squares} of the ROUNDED tile row (what a LayerNorm of the output would read), one entry per
-        // column tile: the consumer GEMM (idb_gemm_desc.ln_stats) adds the tiles_n entries of a row
-        const char* rp = smem + tid * OLD;
+        // column tile: the consumer GEMM (idb_gemm_desc.ln_stats) adds the tiles_n entries of a row.  TPR threads per row, fixed
+        // order + shuffle tree: deterministic
+        constexpr int TPR = THREADS / BM;
+        const int row = tid / TPR, sub = tid % TPR;
+        const char* rp = smem + row * OLD;
         float a = 0.f, q = 0.f;
-        for (int c = 0; c < CPR; ++c) {
+        for (int c = sub; c < CPR; c += TPR) {
             if (n0o + c * 8 < No) {
                 const V8 v = *(const V8*)(rp + c * 16);
 #pragma unroll
@@ -186,15 +245,12 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
                 }
             }
         }
-        *(float2*)(p.rowstat_out + ((long long)(m0 + tid) * p.tiles_n + n0 / BN) * 2) = make_float2(a, q);
-    }
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int q = it * THREADS + tid;
-        const int row = q / CPR, c = q - row * CPR;
-        const int m = m0 + row, n = n0o + c * 8;
-        const int mo = IDB_DBG(p.dbg_skip_store) == 2 ? (m & 127) : m;      // profiling: every tile writes the same L2-resident rows
-        if (q < NCHUNK && m < p.M && n < No) *(V8*)((T*)p.out + (long long)mo * p.out_ld + n) = *(const V8*)(smem + row * OLD + c * 16);
+        for (int o = 1; o < TPR; o <<= 1) {
+            a += __shfl_xor(a, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if (sub == 0 && m0 + row < p.M) *(float2*)(p.rowstat_out + ((long long)(m0 + row) * p.tiles_n + n0 / BN) * 2) = make_float2(a, q);
     }
 }
 
@@ -202,7 +258,7 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
 // outputs / split-K slabs / odd widths.
 template <typename T, int MF, int NF, int WM = 2>
 __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
-                                                  int wm, int wn, int fr, int fg, int kz) {
+                                                  int wm, int wn, int fr, int fg, int kz, bool ln = false, float2 ln_part = {0.f, 0.f}) {
     if (IDB_DBG(p.dbg_skip_store) == 1) {            // profiling experiment: keep the accumulators live, write nothing
         float keep = 0.f;
 #pragma unroll
@@ -292,9 +348,9 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
     }
     if (p.lds_epi) {
         if (p.geglu) {
-            if constexpr ((NF & 1) == 0) idb_lds_epilogue<T, MF, NF, true, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+            if constexpr ((NF & 1) == 0) idb_lds_epilogue<T, MF, NF, true, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, ln, ln_part);
         } else {
-            idb_lds_epilogue<T, MF, NF, false, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg);
+            idb_lds_epilogue<T, MF, NF, false, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, ln, ln_part);
         }
         return;
     }

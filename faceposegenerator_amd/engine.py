@@ -254,12 +254,12 @@ class HipEngine:
             w[f"{n}.ff1.w"] = self._pack_mat(sd[f"{b}.ff.net.0.proj.weight"], geglu=True)
             w[f"{n}.ff1.b"] = self._f32(sd[f"{b}.ff.net.0.proj.bias"][self._geglu_perm(8 * c)])
             # folded-LayerNorm operands (idb_gemm_desc.ln_*): W' = W * gamma along K (one rounding), u = row sums of the ROUNDED W',
-            # v = W beta in fp32; the LoRA-affected ones (qkv, q2) are (re)built by set_lora
+            # v = W beta (+ the layer's bias) in fp32; the LoRA-affected ones (qkv, q2) are (re)built by set_lora
             perm = self._geglu_perm(8 * c).to(self.device)
             wf = self._f32(sd[f"{b}.ff.net.0.proj.weight"])
             w[f"{n}.ff1.wln"] = self._pack_mat(wf * w[f"{n}.ln3.g"][None, :], geglu=True)
             w[f"{n}.ff1.u"] = w[f"{n}.ff1.wln"].float().sum(dim=1).contiguous()
-            w[f"{n}.ff1.v"] = (wf @ w[f"{n}.ln3.b"])[perm].contiguous()
+            w[f"{n}.ff1.v"] = ((wf @ w[f"{n}.ln3.b"])[perm] + w[f"{n}.ff1.b"]).contiguous()   # the layer's bias rides in v (idb_gemm: no bias with ln_stats)
             del wf
             w[f"{n}.qkv.wln"] = torch.empty((3 * c, c), dtype=self.tdt, device=self.device)
             w[f"{n}.q2.wln"] = torch.empty((c, c), dtype=self.tdt, device=self.device)
@@ -656,7 +656,8 @@ class HipEngine:
         W = self.w
         rs = getattr(x, "_rs", None)
         if rs is not None and self._ln_fold:
-            out = self.linear(x, W[f"{pfx}.{wname}.wln"], n, c, ln=(rs[0], rs[1], W[f"{pfx}.{wname}.u"], W[f"{pfx}.{wname}.v"], 1e-5), **kw)
+            kf = {k: v for k, v in kw.items() if k != "bias"}          # the bias is part of .v
+            out = self.linear(x, W[f"{pfx}.{wname}.wln"], n, c, ln=(rs[0], rs[1], W[f"{pfx}.{wname}.u"], W[f"{pfx}.{wname}.v"], 1e-5), **kf)
             if out is not None:
                 return out
         t = self.layernorm(x, rows, c, W[f"{pfx}.{ln_name}.g"], W[f"{pfx}.{ln_name}.b"])

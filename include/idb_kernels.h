@@ -98,8 +98,9 @@ typedef struct {
                                  operand-dtype output, no GEGLU */
     int32_t gn_groups;
     /* LayerNorm folded into the GEMM (BasicTransformerBlock norm1/2/3 -> to_q/k/v, attn2.to_q, ff.net.0): `src` holds the RAW rows
-     * x [M][K = ln_c]; `w` = W scaled by the LayerNorm gamma along K; out = rstd_m (x W'^T - mean_m u) + v (+ bias ...), with
-     * u[n] = sum_k W'[n][k] (of the ROUNDED operand values) and v[n] = sum_k beta[k] W[n][k] (fp32 [n], 16-byte aligned), and the
+     * x [M][K = ln_c]; `w` = W scaled by the LayerNorm gamma along K; out = rstd_m (x W'^T - mean_m u) + v, with
+     * u[n] = sum_k W'[n][k] (of the ROUNDED operand values) and v[n] = sum_k beta[k] W[n][k] + the layer's bias[n] (fp32 [n],
+     * 16-byte aligned; `bias` and `sample_bias` must be NULL: the epilogue keeps two column vectors per fragment in flight), and the
      * per-row statistics taken from ln_stats = the row_stats_out of the GEMM that produced x: fp32 [M][ln_tiles][2] partial
      * {sum, sum of squares} per column tile.  Exact in fp32 (x W'^T - mean u = (x - mean) W'^T term by term).  Only plans that
      * run the LDS-staged epilogue support either side (no split-K, no persistent variant, operand-dtype output): idb_gemm returns

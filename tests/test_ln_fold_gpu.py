@@ -57,7 +57,8 @@ def test_producer_row_stats_and_folded_consumer(eng, m, c, n_out, geglu):
         ref = proj
         wln = eng._pack_mat(w * gamma[None, :])
         u, v, b_ = wln.float().sum(1).contiguous(), (w @ beta).contiguous(), bias
-    out = eng.linear(h, wln, n_out, c, bias=b_, geglu=geglu, ln=(rs[0], rs[1], u, v, 1e-5))
+    # the layer's bias rides in ln_v (idb_gemm rejects bias + ln_stats)
+    out = eng.linear(h, wln, n_out, c, geglu=geglu, ln=(rs[0], rs[1], u, (v + b_).contiguous(), 1e-5))
     assert out is not None
     torch.cuda.synchronize()
     err = (out.float() - ref).abs().max().item()
