@@ -392,10 +392,12 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_rs(const GemmParams p)
 // dropped by the buffer range check — so the store count per wave is a compile-time constant and the K loop can wait
 // for the next tile's loads with a counted vmcnt while these stores are still in flight.
 template <typename T, int MF, int NF, bool GEGLU>
-__device__ __forceinline__ void idb_pl_epilogue(const GemmParams& p, f32x4 (&acc)[MF][NF], int m0, int n0, int wm, int wn, int fr, int fg) {
+__device__ __forceinline__ void idb_pl_epilogue(const GemmParams& p, f32x4 (&acc)[MF][NF], const f32x4 (&cb)[NF], int m0, int n0, int wm, int wn,
+                                                int fr, int fg) {
     using V4 = typename Op<T>::v4;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, IDB_RSRC_FLAGS);
+    const bool hb = p.bias != nullptr;                  // cb holds dummy reads otherwise
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int m = m0 + (wm * MF + i) * 16 + fr;
@@ -414,24 +416,17 @@ __device__ __forceinline__ void idb_pl_epilogue(const GemmParams& p, f32x4 (&acc
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float gt = acc[i][j + 1][e] * p.scale;
-                    if (p.bias && nok) {
-                        o[e] += p.bias[n + e];
-                        gt += p.bias[n + 16 + e];
-                    }
+                    o[e] += hb ? cb[j][e] : 0.f;                        // columns past N are never stored
+                    gt += hb ? cb[j + 1][e] : 0.f;
                     o[e] *= gelu_erf_f(gt);
                 }
             } else {
-                if (nok) {
-                    if (p.bias) {
-                        const f32x4 b4 = *(const f32x4*)(p.bias + n);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += b4[e];
-                    }
-                    if (sb) {
-                        const f32x4 b4 = *(const f32x4*)(sb + n);
+                for (int e = 0; e < 4; ++e) o[e] += hb ? cb[j][e] : 0.f;
+                if (nok && sb) {
+                    const f32x4 b4 = *(const f32x4*)(sb + n);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += b4[e];
-                    }
+                    for (int e = 0; e < 4; ++e) o[e] += b4[e];
                 }
                 if (p.act == 1) {
 #pragma unroll
@@ -523,6 +518,10 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int ct = blockIdx.x, ck = 0;        // compute-side cursor
+    // bias vectors of this lane's NF fragments, loaded at the FIRST K-step of every output tile (one round trip under the tile's
+    // MFMAs): inside the epilogue they sat behind a runtime branch and were awaited one fragment at a time
+    f32x4 cb[NF];
+    const float* bias_or_dummy = p.bias ? p.bias : (const float*)p.w;
     int stores_in_flight = 0;           // 1 / 2: the previous step ended with an epilogue that issued exactly MF*NF / MF*NF/2 stores
     stage(0);
     for (int st = 0; st < total; ++st) {
@@ -536,6 +535,14 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         stores_in_flight = 0;
         if (st + 1 < total) stage(cur ^ 1);
+        if (ck == 0) {
+            const int tn = ct % p.tiles_n;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int nc = min(tn * BN + (wn * NF + j) * 16 + fg * 4, p.N - 4);
+                cb[j] = *(const f32x4*)(bias_or_dummy + (p.bias ? nc : 0));   // raw: first use (and the wait) is in the epilogue
+            }
+        }
         const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
         const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
 #pragma unroll
@@ -555,11 +562,11 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
             const int tm = ct / p.tiles_n, tn = ct - tm * p.tiles_n;
             if (p.geglu) {
                 if constexpr ((NF & 1) == 0) {
-                    idb_pl_epilogue<T, MF, NF, true>(p, acc, tm * BM, tn * BN, wm, wn, fr, fg);
+                    idb_pl_epilogue<T, MF, NF, true>(p, acc, cb, tm * BM, tn * BN, wm, wn, fr, fg);
                     stores_in_flight = 2;
                 }
             } else {
-                idb_pl_epilogue<T, MF, NF, false>(p, acc, tm * BM, tn * BN, wm, wn, fr, fg);
+                idb_pl_epilogue<T, MF, NF, false>(p, acc, cb, tm * BM, tn * BN, wm, wn, fr, fg);
                 stores_in_flight = 1;
             }
 #pragma unroll
@@ -712,6 +719,12 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         const long long tiles = ((M + 127) / 128) * ((d->n + (32 * kTiles[tile].nf) - 1) / (32 * kTiles[tile].nf));
         // measured: +12-15 % on the GEGLU projections (N = 8C, K = C), neutral or slightly negative on the other K = C layers
         if (env_pl && pl_ok && d->geglu && tile == 2 && pl->ktiles <= 24 && tiles >= 256 && d->split_k <= 1) ring3 = 4;
+        // with the bias vectors loaded at the tile's first K-step (round 2) the persistent form also wins the SHORT-K GEGLU
+        // projections once the grid is many rounds deep: K = 320: 593 vs 529 TFLOP/s, K = 640: 795 vs 637 (B_eff = 128,
+        // tools/bench_proj.py).  It cannot fold the LayerNorm (ln_stats -> IDB_EUNSUPPORTED, the caller keeps idb_layernorm); end
+        // to end with that launch back: batch 64 14.76 -> 15.12, batch 8 13.63 -> 13.87, batch 1 6.44 -> 6.52 images/s
+        static const int env_plg = [] { const char* e = getenv("IDB_GEMM_PL_GEGLU_TILES"); return e ? atoi(e) : 512; }();
+        if (env_pl && pl_ok && d->geglu && tile == 9 && env_plg > 0 && tiles >= env_plg && d->split_k <= 1) { tile = 2; ring3 = 4; }
     }
     pl->tile = tile + 10 * ring3;
     const int bm = 16 * kTiles[tile].mf * kTiles[tile].wm, bn = 32 * kTiles[tile].nf;

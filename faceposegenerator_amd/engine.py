@@ -127,6 +127,7 @@ class HipEngine:
         # LayerNorm folded into the consuming projection (to_q/k/v, attn2.to_q, GEGLU-in): row statistics from the producer's epilogue,
         # rstd / mean correction in the consumer's; IDB_LN_FOLD=0 keeps the idb_layernorm launches
         self._ln_fold = os.environ.get("IDB_LN_FOLD", "1") != "0"
+        self._fold_cache: Dict[Tuple[int, int, int, bool], bool] = {}
         self._use_hconv = os.environ.get("IDB_HCONV", "0") == "1"
         self._hconv_tiles = int(os.environ.get("IDB_HCONV_TILES", "512"))
         self._hconv_proj_in = os.environ.get("IDB_HCONV_PROJ_IN", "1") != "0"      # Transformer2DModel.norm + proj_in fused as well
@@ -665,6 +666,23 @@ class HipEngine:
         self.arena.free(t)
         return out
 
+    def folds(self, x, rows: int, c: int, n: int, geglu: bool = False) -> bool:
+        """Will ``ln_linear`` fold the LayerNorm of ``x`` [rows][c] into its [n][c] projection?  (The consumer's plan must run the
+        LDS-staged epilogue; the persistent GEGLU form of the deep grids does not.)  Asked BEFORE the producer GEMM so that it emits
+        row statistics only for a consumer that reads them.  Cached per shape."""
+        if not self._ln_fold:
+            return False
+        key = (rows, c, n, geglu)
+        hit = self._fold_cache.get(key)
+        if hit is None:
+            d = L.GemmDesc()
+            d.dtype, d.batch, d.out_h, d.out_w, d.stride, d.n, d.nsrc = self.dt, rows, 1, 1, 1, n, 1
+            d.src[0].ptr, d.src[0].channels, d.src[0].taps, d.src[0].in_h, d.src[0].in_w = x.data_ptr(), c, 1, 1, 1
+            d.w, d.geglu = x.data_ptr(), int(geglu)
+            d.out, d.out_dtype, d.out_ld = x.data_ptr(), self.dt, (n // 2 if geglu else n)
+            hit = self._fold_cache[key] = self.lib.idb_gemm_row_stats_tiles(C.byref(d)) > 0
+        return hit
+
     def _free_rs(self, x) -> None:
         rs = getattr(x, "_rs", None)
         if rs is not None:
@@ -765,7 +783,7 @@ class HipEngine:
             self.arena.free(part)
         else:
             xn = self.groupnorm(x, c, None, 0, batch, hw, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
-            h0 = self.linear(xn, W[f"{n}.proj_in.w"], c, c, bias=W[f"{n}.proj_in.b"], row_stats=True)
+            h0 = self.linear(xn, W[f"{n}.proj_in.w"], c, c, bias=W[f"{n}.proj_in.b"], row_stats=self.folds(xn, m, c, 3 * c))
             self.arena.free(xn)
         # self-attention
         qkv = self.ln_linear(h0, m, c, n, "ln1", "qkv", 3 * c)
@@ -773,7 +791,7 @@ class HipEngine:
         p = qkv.data_ptr()
         o = self.attention(qkv, 3 * c, p + 2 * c, p + 4 * c, 3 * c, batch, a.heads, hw, hw, hw)
         self.arena.free(qkv)
-        h1 = self.linear(o, W[f"{n}.o1.w"], c, c, bias=W[f"{n}.o1.b"], residual=h0, row_stats=True)
+        h1 = self.linear(o, W[f"{n}.o1.w"], c, c, bias=W[f"{n}.o1.b"], residual=h0, row_stats=self.folds(o, m, c, c))
         self.arena.free(o)
         self.arena.free(h0)
         # cross-attention (K/V of the prompt embeddings are per-call constants)
@@ -782,7 +800,7 @@ class HipEngine:
         kp = kv.data_ptr()
         o = self.attention(q2, c, kp, kp + 2 * c, 2 * c, batch, a.heads, hw, n_ctx, n_ctx)
         self.arena.free(q2)
-        h2 = self.linear(o, W[f"{n}.o2.w"], c, c, bias=W[f"{n}.o2.b"], residual=h1, row_stats=True)
+        h2 = self.linear(o, W[f"{n}.o2.w"], c, c, bias=W[f"{n}.o2.b"], residual=h1, row_stats=self.folds(o, m, c, 8 * c, True))
         self.arena.free(o)
         self.arena.free(h1)
         # GEGLU feed-forward
