@@ -392,18 +392,20 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_rs(const GemmParams p)
 // dropped by the buffer range check — so the store count per wave is a compile-time constant and the K loop can wait
 // for the next tile's loads with a counted vmcnt while these stores are still in flight.
 template <typename T, int MF, int NF, bool GEGLU>
-__device__ __forceinline__ void idb_pl_epilogue(const GemmParams& p, f32x4 (&acc)[MF][NF], const f32x4 (&cb)[NF], int m0, int n0, int wm, int wn,
-                                                int fr, int fg) {
+__device__ __forceinline__ void idb_pl_epilogue(const GemmParams& p, f32x4 (&acc)[MF][NF], const f32x4 (&cb)[NF], const f32x4 (&cu)[NF],
+                                                const float2 (&mr)[MF], int m0, int n0, int wm, int wn, int fr, int fg) {
     using V4 = typename Op<T>::v4;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, IDB_RSRC_FLAGS);
-    const bool hb = p.bias != nullptr;                  // cb holds dummy reads otherwise
+    const bool ln = p.ln_stats != nullptr;              // folded LayerNorm: out = rstd (scale acc - mean u) + v, cb = ln_v, cu = ln_u
+    const bool hb = p.bias != nullptr || ln;            // cb holds dummy reads otherwise
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int m = m0 + (wm * MF + i) * 16 + fr;
         const bool mok = m < p.M;
         const int mc = mok ? m : 0;
         const float* sb = p.sbias ? p.sbias + (long long)(mc / p.HW) * p.sbias_ld : nullptr;
+        const float rs = ln ? mr[i].y * p.scale : p.scale, kb = ln ? -mr[i].x * mr[i].y : 0.f;
 #pragma unroll
         for (int j = 0; j < NF; j += (GEGLU ? 2 : 1)) {
             const int n = n0 + (wn * NF + j) * 16 + fg * 4;               // packed row (value part for GEGLU)
@@ -411,11 +413,11 @@ __device__ __forceinline__ void idb_pl_epilogue(const GemmParams& p, f32x4 (&acc
             const bool nok = GEGLU ? (n + 16 < p.N) : (n < p.N);
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * p.scale;
+            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] * rs + (ln ? kb * cu[j][e] : 0.f);
             if constexpr (GEGLU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float gt = acc[i][j + 1][e] * p.scale;
+                    float gt = acc[i][j + 1][e] * rs + (ln ? kb * cu[j + 1][e] : 0.f);
                     o[e] += hb ? cb[j][e] : 0.f;                        // columns past N are never stored
                     gt += hb ? cb[j + 1][e] : 0.f;
                     o[e] *= gelu_erf_f(gt);
@@ -520,8 +522,16 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
     int ct = blockIdx.x, ck = 0;        // compute-side cursor
     // bias vectors of this lane's NF fragments, loaded at the FIRST K-step of every output tile (one round trip under the tile's
     // MFMAs): inside the epilogue they sat behind a runtime branch and were awaited one fragment at a time
-    f32x4 cb[NF];
-    const float* bias_or_dummy = p.bias ? p.bias : (const float*)p.w;
+    f32x4 cb[NF], cu[NF];
+    const bool ln = p.ln_stats != nullptr;
+    const float* bias_or_dummy = ln ? p.ln_v : (p.bias ? p.bias : (const float*)p.w);
+    const bool has_cb = ln || p.bias;
+    // folded LayerNorm: the ln_nt partial {sum, sum of squares} of a tile row are split over its four fg lane groups (two loads
+    // per lane and row, ln_nt <= 8; more: an accumulating loop), loaded RAW at the tile's first K-step and reduced at the second
+    // (behind that step's vmcnt(0) + barrier: no exposed round trip); {mean, rstd} then wait in mr for the epilogue
+    float2 sp[MF][2], mr[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) mr[i] = make_float2(0.f, 1.f);
     int stores_in_flight = 0;           // 1 / 2: the previous step ended with an epilogue that issued exactly MF*NF / MF*NF/2 stores
     stage(0);
     for (int st = 0; st < total; ++st) {
@@ -534,13 +544,50 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
         else
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         stores_in_flight = 0;
+        if (ln && ck == 1) {                            // the statistics loads of step 0 have landed (vmcnt(0) above)
+            const float inv_c = 1.0f / (float)p.ln_c;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                float a = sp[i][0].x + sp[i][1].x, q = sp[i][0].y + sp[i][1].y;
+                a += __shfl_xor(a, 16, 64);
+                q += __shfl_xor(q, 16, 64);
+                a += __shfl_xor(a, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                const float mean = a * inv_c;
+                double var = (double)q * (double)inv_c - (double)mean * (double)mean;     // see idb_ln_row_table
+                if (var < 0.0) var = 0.0;
+                mr[i] = make_float2(mean, __builtin_amdgcn_rsqf((float)var + p.ln_eps));
+            }
+        }
         if (st + 1 < total) stage(cur ^ 1);
         if (ck == 0) {
-            const int tn = ct % p.tiles_n;
+            const int tm = ct / p.tiles_n, tn = ct - tm * p.tiles_n;
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 const int nc = min(tn * BN + (wn * NF + j) * 16 + fg * 4, p.N - 4);
-                cb[j] = *(const f32x4*)(bias_or_dummy + (p.bias ? nc : 0));   // raw: first use (and the wait) is in the epilogue
+                cb[j] = *(const f32x4*)(bias_or_dummy + (has_cb ? nc : 0));   // raw: first use (and the wait) is in the epilogue
+                cu[j] = *(const f32x4*)(ln ? p.ln_u + nc : bias_or_dummy);
+            }
+            if (ln) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    const int m = min(tm * BM + (wm * MF + i) * 16 + fr, p.M - 1);
+                    const float* ps = p.ln_stats + (long long)m * p.ln_nt * 2;
+                    if (p.ln_nt <= 8) {
+                        const float2 v0 = *(const float2*)(ps + 2 * min(fg, p.ln_nt - 1)), v1 = *(const float2*)(ps + 2 * min(fg + 4, p.ln_nt - 1));
+                        sp[i][0] = fg < p.ln_nt ? v0 : make_float2(0.f, 0.f);
+                        sp[i][1] = fg + 4 < p.ln_nt ? v1 : make_float2(0.f, 0.f);
+                    } else {
+                        float a = 0.f, q = 0.f;
+                        for (int t = fg; t < p.ln_nt; t += 4) {
+                            const float2 v = *(const float2*)(ps + 2 * t);
+                            a += v.x;
+                            q += v.y;
+                        }
+                        sp[i][0] = make_float2(a, q);
+                        sp[i][1] = make_float2(0.f, 0.f);
+                    }
+                }
             }
         }
         const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
@@ -562,11 +609,11 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
             const int tm = ct / p.tiles_n, tn = ct - tm * p.tiles_n;
             if (p.geglu) {
                 if constexpr ((NF & 1) == 0) {
-                    idb_pl_epilogue<T, MF, NF, true>(p, acc, cb, tm * BM, tn * BN, wm, wn, fr, fg);
+                    idb_pl_epilogue<T, MF, NF, true>(p, acc, cb, cu, mr, tm * BM, tn * BN, wm, wn, fr, fg);
                     stores_in_flight = 2;
                 }
             } else {
-                idb_pl_epilogue<T, MF, NF, false>(p, acc, cb, tm * BM, tn * BN, wm, wn, fr, fg);
+                idb_pl_epilogue<T, MF, NF, false>(p, acc, cb, cu, mr, tm * BM, tn * BN, wm, wn, fr, fg);
                 stores_in_flight = 1;
             }
 #pragma unroll
@@ -884,6 +931,23 @@ static bool gemm_uses_lds_epilogue(const idb_gemm_desc* d, const Plan& pl) {
            (!d->residual || idb_aligned16(d->residual));
 }
 
+// a folded LayerNorm needs the LDS-staged epilogue, or the persistent variant with >= 2 K-steps (statistics loaded at the first,
+// reduced at the second)
+static bool gemm_folds_ln(const idb_gemm_desc* d, const Plan& pl) {
+    if (d->nsrc != 1 || d->src[0].taps != 1 || d->n % 4 || d->bias || d->sample_bias) return false;
+    // persistent variant: built and tested, but off unless asked for (flags bit 8 / IDB_GEMM_PL_LN=1) — measured on one box, the
+    // producer's statistics pass + the fold cost what the idb_layernorm launch costs: batch 64 14.77 -> 14.65 images/s (twice),
+    // batch 1 6.645 vs 6.641 with 15 fewer launches
+    static const int env_pl_ln = [] { const char* e = getenv("IDB_GEMM_PL_LN"); return e ? atoi(e) : 0; }();
+    if (pl.tile / 10 == 4) return (env_pl_ln || (d->flags & 256)) && pl.ktiles >= 2;
+    return gemm_uses_lds_epilogue(d, pl);
+}
+
+extern "C" int32_t idb_gemm_folds_layernorm(const idb_gemm_desc* d) {
+    Plan pl;
+    return plan_gemm(d, &pl) == IDB_OK && gemm_folds_ln(d, pl) ? 1 : 0;
+}
+
 extern "C" int32_t idb_gemm_row_stats_tiles(const idb_gemm_desc* d) {
     Plan pl;
     if (plan_gemm(d, &pl) != IDB_OK || !gemm_uses_lds_epilogue(d, pl)) return 0;
@@ -968,8 +1032,9 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
                      (!d->residual || idb_aligned16(d->residual))) ? 1 : 0;
     }
     if (d->row_stats_out || d->ln_stats) {
-        if (!p.lds_epi || pl.tile / 10 == 3) {
-            idb_set_error("idb_gemm: row_stats_out / ln_stats need a plan with the LDS-staged epilogue (no split-K, no persistent / register-staged variant)");
+        if ((d->row_stats_out && (!p.lds_epi || pl.tile / 10 == 3)) || (d->ln_stats && !gemm_folds_ln(d, pl))) {
+            idb_set_error("idb_gemm: row_stats_out needs a plan with the LDS-staged epilogue (no split-K, no persistent / register-staged variant); "
+                          "ln_stats that or the persistent variant");
             return IDB_EUNSUPPORTED;
         }
         IDB_REQUIRE(!d->ln_stats || (d->ln_tiles > 0 && d->ln_u && d->ln_v && idb_aligned16(d->ln_u) && idb_aligned16(d->ln_v) && ((uintptr_t)d->ln_stats & 7) == 0 &&

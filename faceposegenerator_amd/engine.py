@@ -447,7 +447,7 @@ class HipEngine:
                 rs_buf = self.arena.alloc((m * nt * 2,), torch.float32)
                 d.row_stats_out = rs_buf.data_ptr()
         if ln is not None:
-            if self.lib.idb_gemm_row_stats_tiles(C.byref(d)) == 0:      # this plan cannot fold (split-K / persistent): caller keeps idb_layernorm
+            if self.lib.idb_gemm_folds_layernorm(C.byref(d)) == 0:      # this plan cannot fold (split-K): caller keeps idb_layernorm
                 if own_out:
                     self.arena.free(out)
                 if rs_buf is not None:
@@ -668,7 +668,7 @@ class HipEngine:
 
     def folds(self, x, rows: int, c: int, n: int, geglu: bool = False) -> bool:
         """Will ``ln_linear`` fold the LayerNorm of ``x`` [rows][c] into its [n][c] projection?  (The consumer's plan must run the
-        LDS-staged epilogue; the persistent GEGLU form of the deep grids does not.)  Asked BEFORE the producer GEMM so that it emits
+        LDS-staged epilogue or the persistent variant; a split-K plan does not.)  Asked BEFORE the producer GEMM so that it emits
         row statistics only for a consumer that reads them.  Cached per shape."""
         if not self._ln_fold:
             return False
@@ -680,7 +680,7 @@ class HipEngine:
             d.src[0].ptr, d.src[0].channels, d.src[0].taps, d.src[0].in_h, d.src[0].in_w = x.data_ptr(), c, 1, 1, 1
             d.w, d.geglu = x.data_ptr(), int(geglu)
             d.out, d.out_dtype, d.out_ld = x.data_ptr(), self.dt, (n // 2 if geglu else n)
-            hit = self._fold_cache[key] = self.lib.idb_gemm_row_stats_tiles(C.byref(d)) > 0
+            hit = self._fold_cache[key] = self.lib.idb_gemm_folds_layernorm(C.byref(d)) > 0
         return hit
 
     def _free_rs(self, x) -> None:

@@ -85,7 +85,7 @@ typedef struct {
     int32_t split_k;          /* 0 = library heuristic, >=1 explicit */
     int32_t tile;             /* 0 = heuristic; else a tile config id as idb_gemm_plan reports it (tests and measurements) */
     float out_scale;          /* multiplies the accumulator before bias (0 => 1.0) */
-    int32_t flags;            /* profiling/testing only — bit 0: skip the split-K reduce launch (`out` not written); bit 1: skip the epilogue stores; bit 2: force the direct (non-LDS-staged) epilogue; bit 3: force the two-launch split-K reduce; bit 4: in-kernel split-K reduce (default: separate reduce launch, which measured faster) */
+    int32_t flags;            /* profiling/testing only — bit 0: skip the split-K reduce launch (`out` not written); bit 1: skip the epilogue stores; bit 2: force the direct (non-LDS-staged) epilogue; bit 3: force the two-launch split-K reduce; bit 4: in-kernel split-K reduce (default: separate reduce launch, which measured faster); bit 8: let the persistent variant fold a LayerNorm (ln_stats; default: IDB_EUNSUPPORTED there, the separate idb_layernorm measured no slower) */
     int32_t act;              /* 0 none, 1 exact GELU applied to (acc*scale + bias) (CLIP MLP fc1); not with residual/GEGLU */
     uint32_t* counters;       /* optional: >= counters_len zeroed uint32 on the device, private to the stream; used only with
                                  flags bit 4: a split-K launch then reduces inside the GEMM (the last-arriving workgroup of a
@@ -102,9 +102,10 @@ typedef struct {
      * u[n] = sum_k W'[n][k] (of the ROUNDED operand values) and v[n] = sum_k beta[k] W[n][k] + the layer's bias[n] (fp32 [n],
      * 16-byte aligned; `bias` and `sample_bias` must be NULL: the epilogue keeps two column vectors per fragment in flight), and the
      * per-row statistics taken from ln_stats = the row_stats_out of the GEMM that produced x: fp32 [M][ln_tiles][2] partial
-     * {sum, sum of squares} per column tile.  Exact in fp32 (x W'^T - mean u = (x - mean) W'^T term by term).  Only plans that
-     * run the LDS-staged epilogue support either side (no split-K, no persistent variant, operand-dtype output): idb_gemm returns
-     * IDB_EUNSUPPORTED otherwise and the caller keeps idb_layernorm; idb_gemm_row_stats_tiles tells beforehand (0 = unsupported). */
+     * {sum, sum of squares} per column tile.  Exact in fp32 (x W'^T - mean u = (x - mean) W'^T term by term).  row_stats_out needs
+     * a plan that runs the LDS-staged epilogue (no split-K, no persistent variant, operand-dtype output), ln_stats that or the
+     * persistent variant: idb_gemm returns IDB_EUNSUPPORTED otherwise and the caller keeps idb_layernorm; idb_gemm_row_stats_tiles
+     * (producer side, 0 = unsupported) and idb_gemm_folds_layernorm (consumer side) tell beforehand. */
     float* row_stats_out;     /* optional out: [M][idb_gemm_row_stats_tiles(d)][2] */
     const float* ln_stats;    /* optional in */
     int32_t ln_tiles;
@@ -121,9 +122,10 @@ size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);
  * 4: 64x64 (8 waves), 5: 128x32, 6-9: 64x160 / 64x128 / 128x160 / 128x128 with 8 waves; variant 0/1: 2-/3-stage LDS ring,
  * 4: persistent), split-K factor and workgroup count.  Host-only, no GPU call. */
 int idb_gemm_plan(const idb_gemm_desc* d, int32_t* tile, int32_t* split_k, int32_t* blocks);
-/* Column tiles of the plan idb_gemm would run for `d` if that plan can emit row statistics / apply a folded LayerNorm (LDS-staged
- * epilogue), else 0. */
+/* Column tiles of the plan idb_gemm would run for `d` if that plan can emit row statistics (LDS-staged epilogue), else 0. */
 int32_t idb_gemm_row_stats_tiles(const idb_gemm_desc* d);
+/* 1 if the plan idb_gemm would run for `d` (bias / sample_bias NULL, one 1x1 source) can apply a folded LayerNorm (ln_*). */
+int32_t idb_gemm_folds_layernorm(const idb_gemm_desc* d);
 int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight packing (run once at load; SURVEY.md §8b "idb_pack_*"). src is fp32 in torch layout. */

@@ -27,7 +27,9 @@ def _rand(shape, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("m,c,n_out,geglu", [(512, 320, 960, False), (8192, 320, 320, False), (2048, 640, 1920, False), (300, 128, 256, False),
-                                             (512, 1280, 3840, False), (4096, 320, 2560, True), (1024, 640, 5120, True), (200, 128, 1024, True)])
+                                             (512, 1280, 3840, False), (4096, 320, 2560, True), (1024, 640, 5120, True), (200, 128, 1024, True),
+                                             # persistent-variant consumers: ragged M; 4 and 20 partials per row (> 8: the looped loads)
+                                             (4000, 320, 2560, True), (16384, 640, 5120, True), (512, 1280, 10240, True)])
 def test_producer_row_stats_and_folded_consumer(eng, m, c, n_out, geglu):
     # producer: h = a Wp^T + b + res  (attn.to_out + residual), emitting the row statistics of the rounded h
     a = _rand((m, c), 1).to(eng.tdt)
@@ -58,7 +60,7 @@ def test_producer_row_stats_and_folded_consumer(eng, m, c, n_out, geglu):
         wln = eng._pack_mat(w * gamma[None, :])
         u, v, b_ = wln.float().sum(1).contiguous(), (w @ beta).contiguous(), bias
     # the layer's bias rides in ln_v (idb_gemm rejects bias + ln_stats)
-    out = eng.linear(h, wln, n_out, c, geglu=geglu, ln=(rs[0], rs[1], u, (v + b_).contiguous(), 1e-5))
+    out = eng.linear(h, wln, n_out, c, geglu=geglu, ln=(rs[0], rs[1], u, (v + b_).contiguous(), 1e-5), flags=256)   # bit 8: also in the persistent variant
     assert out is not None
     torch.cuda.synchronize()
     err = (out.float() - ref).abs().max().item()
@@ -70,6 +72,24 @@ def test_producer_row_stats_and_folded_consumer(eng, m, c, n_out, geglu):
     torch.cuda.synchronize()
     err_old = (old.float() - ref).abs().max().item()
     assert err <= max(2.0 * err_old, tol / 2)
+
+
+def test_persistent_consumers_are_covered(eng):
+    """The GEGLU cases above with >= 512 tiles (or K >= 1024 and >= 256) run idb_gemm_kernel_pl: plan variant 4."""
+    import ctypes as C
+    from faceposegenerator_amd import _lib as L
+    x = torch.zeros(16, device=DEV)
+    for (m, c, n_out, want) in [(4000, 320, 2560, True), (16384, 640, 5120, True), (512, 1280, 10240, True), (1024, 640, 5120, False)]:
+        d = L.GemmDesc()
+        d.dtype, d.batch, d.out_h, d.out_w, d.stride, d.n, d.nsrc = eng.dt, m, 1, 1, 1, n_out, 1
+        d.src[0].ptr, d.src[0].channels, d.src[0].taps, d.src[0].in_h, d.src[0].in_w = x.data_ptr(), c, 1, 1, 1
+        d.w, d.geglu, d.out, d.out_dtype, d.out_ld = x.data_ptr(), 1, x.data_ptr(), eng.dt, n_out // 2
+        tile, sk, blocks = C.c_int32(), C.c_int32(), C.c_int32()
+        L.check(eng.lib.idb_gemm_plan(C.byref(d), C.byref(tile), C.byref(sk), C.byref(blocks)), "idb_gemm_plan")
+        assert (tile.value // 10 == 4) == want, (m, c, n_out, tile.value)
+        assert eng.lib.idb_gemm_folds_layernorm(C.byref(d)) == (0 if want else 1)      # off by default in the persistent variant ...
+        d.flags = 256
+        assert eng.lib.idb_gemm_folds_layernorm(C.byref(d)) == 1                        # ... on with flags bit 8
 
 
 def test_split_k_plans_decline_the_fold(eng):
