@@ -106,9 +106,34 @@ __device__ __forceinline__ void idb_ln_row_table(const GemmParams& p, float2* ro
     }
 }
 
+// Column vectors of a lane's NF accumulator fragments, loaded ONCE and unconditionally (an absent term reads a valid dummy address
+// and is dropped by a value select at the use): the loads are independent and all in flight together.  Loads behind
+// `if (p.bias)` / `if (sb)` inside the (i, j) loop were issued and awaited one by one — 2-4 exposed L2 round trips per fragment,
+// measured +20-70 % on the K = C projections once the folded-LayerNorm vectors joined them.
+// Two vectors per fragment (more in flight costs the 8-wave tiles their second workgroup per CU in VGPRs):
+//   ca = bias, or ln_v of a folded LayerNorm (the caller adds the layer's bias into ln_v; idb_gemm rejects bias + ln_stats)
+//   cb = the per-sample bias when the whole tile lies in one sample (else per-row loads in the epilogue), or ln_u
+// The values stay RAW (no arithmetic here), so the wait lands at the first use.
+template <int NF, int BM>
+__device__ __forceinline__ void idb_load_colvecs(const GemmParams& p, int m0, int n0, int wn, int fg, f32x4 (&ca)[NF], f32x4 (&cb)[NF]) {
+    const bool ln = p.ln_stats != nullptr;
+    const int m_last = min(m0 + BM, p.M) - 1;
+    const bool sb_tile = p.sbias && (m0 / p.HW == m_last / p.HW);
+    const float* dummy = (const float*)p.w;
+    const float* pa = ln ? p.ln_v : p.bias;
+    const float* pb = ln ? p.ln_u : (sb_tile ? p.sbias + (long long)(m0 / p.HW) * p.sbias_ld : nullptr);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int nc = min(n0 + (wn * NF + j) * 16 + fg * 4, p.N - 4);
+        ca[j] = *(const f32x4*)(pa ? pa + nc : dummy);
+        cb[j] = *(const f32x4*)(pb ? pb + nc : dummy);
+    }
+}
+
 template <typename T, int MF, int NF, bool GEGLU, int WM = 2>
-__device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
-                                                 int wm, int wn, int fr, int fg, bool ln = false, float2 ln_part = {0.f, 0.f}) {
+__device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], const f32x4 (&ca)[NF],
+                                                 const f32x4 (&cb)[NF], int m0, int n0, int tid, int wm, int wn, int fr, int fg, bool ln = false,
+                                                 float2 ln_part = {0.f, 0.f}) {
     using V8 = typename Op<T>::v8;
     using V4 = typename Op<T>::v4;
     constexpr int BM = 16 * MF * WM, BN = 32 * NF, THREADS = 128 * WM;
@@ -136,30 +161,10 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
         }
         __syncthreads();
     }
-    // Column vectors of this lane's NF fragments, loaded ONCE before the row loop and unconditionally (an absent term reads a
-    // valid dummy address and is dropped by a value select): the loads are then independent and all in flight together.  Loads
-    // behind `if (p.bias)` / `if (sb)` inside the (i, j) loop were issued and awaited one by one — 2-4 exposed L2 round trips
-    // per fragment, measured +20-70 % on the K = C projections once the folded-LayerNorm vectors joined them.
-    // Two vectors per fragment (more in flight costs the 8-wave tiles their second workgroup per CU in VGPRs):
-    //   ca = bias, or ln_v of a folded LayerNorm (the caller adds the layer's bias into ln_v; idb_gemm rejects bias + ln_stats)
-    //   cb = the per-sample bias when the whole tile lies in one sample, or ln_u
+    // ca / cb: idb_load_colvecs (raw values; which terms exist is decided here)
     const int m_last = min(m0 + BM, p.M) - 1;
     const bool sb_tile = p.sbias && (m0 / p.HW == m_last / p.HW);      // else (HW < BM): per-row loads below
-    const float* dummy = (const float*)p.w;
-    const float* pa = rowtab ? p.ln_v : p.bias;
-    const float* pb = rowtab ? p.ln_u : (sb_tile ? p.sbias + (long long)(m0 / p.HW) * p.sbias_ld : nullptr);
-    f32x4 ca[NF], cb[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int nc = min(n0 + (wn * NF + j) * 16 + fg * 4, p.N - 4);
-        const f32x4 a4 = *(const f32x4*)(pa ? pa + nc : dummy);
-        const f32x4 b4 = *(const f32x4*)(pb ? pb + nc : dummy);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ca[j][e] = pa ? a4[e] : 0.f;
-            cb[j][e] = pb ? b4[e] : 0.f;
-        }
-    }
+    const bool has_a = rowtab || p.bias, has_b = rowtab || sb_tile;
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int row = (wm * MF + i) * 16 + fr;
@@ -178,8 +183,8 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
                 for (int e = 0; e < 4; ++e) {
                     float v = rs * acc[i][j][e], gt = rs * acc[i][j + 1][e];
                     if (nv + 16 < p.N) {
-                        v += kb * cb[j][e] + ca[j][e];
-                        gt += kb * cb[j + 1][e] + ca[j + 1][e];
+                        v += (has_b ? kb * cb[j][e] : 0.f) + (has_a ? ca[j][e] : 0.f);
+                        gt += (has_b ? kb * cb[j + 1][e] : 0.f) + (has_a ? ca[j + 1][e] : 0.f);
                     }
                     o[e] = v * gelu_erf_f(gt);
                 }
@@ -196,7 +201,7 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
                 for (int e = 0; e < 4; ++e) o[e] = rs * acc[i][j][e];
                 if (n < p.N) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += kb * cb[j][e] + ca[j][e];
+                    for (int e = 0; e < 4; ++e) o[e] += (has_b ? kb * cb[j][e] : 0.f) + (has_a ? ca[j][e] : 0.f);
                     if (sb) {
                         const f32x4 b4 = *(const f32x4*)(sb + n);
 #pragma unroll
@@ -254,11 +259,12 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
     }
 }
 
-// Everything after the K loop: LDS-staged coalesced epilogue for operand-dtype outputs, direct epilogue for fp32
-// outputs / split-K slabs / odd widths.
-template <typename T, int MF, int NF, int WM = 2>
-__device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid,
-                                                  int wm, int wn, int fr, int fg, int kz, bool ln = false, float2 ln_part = {0.f, 0.f}) {
+// Everything after the K loop: LDS-staged coalesced epilogue for operand-dtype outputs, direct epilogue for fp32 outputs /
+// split-K slabs / odd widths.  PRE: ca / cb were loaded by the kernel before its K loop (idb_load_colvecs).
+template <typename T, int MF, int NF, int WM = 2, bool PRE = false>
+__device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], f32x4 (&ca)[NF], f32x4 (&cb)[NF], int m0,
+                                                  int n0, int tid, int wm, int wn, int fr, int fg, int kz, bool ln = false,
+                                                  float2 ln_part = {0.f, 0.f}) {
     if (IDB_DBG(p.dbg_skip_store) == 1) {            // profiling experiment: keep the accumulators live, write nothing
         float keep = 0.f;
 #pragma unroll
@@ -347,10 +353,11 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
         }
     }
     if (p.lds_epi) {
+        if constexpr (!PRE) idb_load_colvecs<NF, 16 * MF * WM>(p, m0, n0, wn, fg, ca, cb);
         if (p.geglu) {
-            if constexpr ((NF & 1) == 0) idb_lds_epilogue<T, MF, NF, true, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, ln, ln_part);
+            if constexpr ((NF & 1) == 0) idb_lds_epilogue<T, MF, NF, true, WM>(p, smem, acc, ca, cb, m0, n0, tid, wm, wn, fr, fg, ln, ln_part);
         } else {
-            idb_lds_epilogue<T, MF, NF, false, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, ln, ln_part);
+            idb_lds_epilogue<T, MF, NF, false, WM>(p, smem, acc, ca, cb, m0, n0, tid, wm, wn, fr, fg, ln, ln_part);
         }
         return;
     }
@@ -433,6 +440,16 @@ __device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* sme
             }
         }
     }
+}
+
+// the form every kernel uses: column vectors loaded at the head of the epilogue.  (PRE = loading them before the K loop of the
+// 64-row tiles, older than every LDS-DMA, was measured: batch 1 6.653 -> 6.630 images/s, batch 8 13.85 -> 13.68 — the 16-40 more
+// live VGPRs and the later first DMA cost more than the one L2 round trip saved.)
+template <typename T, int MF, int NF, int WM = 2>
+__device__ __forceinline__ void idb_gemm_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[MF][NF], int m0, int n0, int tid, int wm, int wn,
+                                                  int fr, int fg, int kz, bool ln = false, float2 ln_part = {0.f, 0.f}) {
+    f32x4 ca[NF], cb[NF];
+    idb_gemm_epilogue<T, MF, NF, WM, false>(p, smem, acc, ca, cb, m0, n0, tid, wm, wn, fr, fg, kz, ln, ln_part);
 }
 
 
