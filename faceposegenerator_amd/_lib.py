@@ -19,7 +19,7 @@ IDB_MAX_SRC = 4
 # every symbol include/idb_kernels.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "idb_version", "idb_launch_count", "idb_last_error", "idb_device_check",
-    "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm_row_stats_tiles", "idb_gemm_folds_layernorm", "idb_gemm",
+    "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm_row_stats_tiles", "idb_gemm_folds_layernorm", "idb_gemm_emits_gn_partials", "idb_gemm",
     "idb_pack_conv_weight", "idb_pack_matrix", "idb_lora_merge", "idb_lora_merge_scaled",
     "idb_groupnorm_workspace_bytes", "idb_groupnorm", "idb_layernorm", "idb_groupnorm_stats",
     "idb_hconv_workspace_bytes", "idb_hconv_plan", "idb_hconv",
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
         "idb_gemm": (C.c_int, [C.POINTER(GemmDesc), vp, sz, vp]),
         "idb_gemm_row_stats_tiles": (i32, [C.POINTER(GemmDesc)]),
         "idb_gemm_folds_layernorm": (i32, [C.POINTER(GemmDesc)]),
+        "idb_gemm_emits_gn_partials": (i32, [C.POINTER(GemmDesc), i32]),
         "idb_lora_merge_scaled": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, i32, vp]),
         "idb_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
         "idb_pack_matrix": (C.c_int, [vp, vp, i64, i64, i32, i32, vp]),

@@ -943,6 +943,21 @@ static bool gemm_folds_ln(const idb_gemm_desc* d, const Plan& pl) {
     return gemm_uses_lds_epilogue(d, pl);
 }
 
+// the GEMM's own LDS-staged epilogue can emit the first GroupNorm pass of the output (no split-K, whole groups per column tile)
+static bool gemm_epilogue_emits_gn(const idb_gemm_desc* d, const Plan& pl, int groups) {
+    if (pl.tile / 10 > 2 || d->geglu || !gemm_uses_lds_epilogue(d, pl)) return false;
+    const TileCfg& t = kTiles[pl.tile % 10];
+    return idb_epilogue_emits_gn(16 * t.mf * t.wm, 32 * t.nf, 128 * t.wm, pl.M, d->n, groups) && (long long)d->out_h * d->out_w % 64 == 0 &&
+           d->out_ld == d->n;
+}
+
+extern "C" int32_t idb_gemm_emits_gn_partials(const idb_gemm_desc* d, int32_t groups) {
+    Plan pl;
+    if (plan_gemm(d, &pl) != IDB_OK) return 0;
+    if (pl.splitk > 1) return d->out_dtype == d->dtype && pl.M % 64 == 0 && gn_reduce_slice(d->n, groups) != 0 ? 1 : 0;
+    return gemm_epilogue_emits_gn(d, pl, groups) ? 2 : 0;
+}
+
 extern "C" int32_t idb_gemm_folds_layernorm(const idb_gemm_desc* d) {
     Plan pl;
     return plan_gemm(d, &pl) == IDB_OK && gemm_folds_ln(d, pl) ? 1 : 0;
@@ -1042,6 +1057,10 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
                     "idb_gemm: ln_stats needs ln_tiles > 0, aligned ln_u / ln_v, one 1x1 source, n %% 4 == 0, and no bias / sample_bias "
                     "(add the layer's bias into ln_v)");
         IDB_REQUIRE(!d->row_stats_out || (((uintptr_t)d->row_stats_out & 7) == 0 && !d->geglu), "idb_gemm: row_stats_out must be 8-byte aligned, no GEGLU");
+    }
+    if (d->gn_partials && pl.splitk == 1 && !(d->flags & 1) && gemm_epilogue_emits_gn(d, pl, d->gn_groups)) {
+        p.gn_part = d->gn_partials;          // launch_all's idb_finish_splitk then has nothing left to launch
+        p.gn_groups = d->gn_groups;
     }
     p.rowstat_out = d->row_stats_out;
     p.ln_stats = d->ln_stats;

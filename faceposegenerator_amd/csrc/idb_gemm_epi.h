@@ -38,6 +38,10 @@ struct GemmParams {
     const float* ln_v;
     int ln_nt, ln_c;
     float ln_eps;
+    // first GroupNorm pass of the output from the LDS-staged epilogue (no split-K: no reduce launch to ride on): non-null only when
+    // the tile's column range holds whole groups (host: idb_epilogue_emits_gn)
+    float* gn_part;
+    int gn_groups;
 };
 
 // voffset of a lane that must read zeros: beyond num_records of every descriptor (all < 2^31), and
@@ -256,6 +260,44 @@ __device__ __forceinline__ void idb_lds_epilogue(const GemmParams& p, char* smem
             q += __shfl_xor(q, o, 64);
         }
         if (sub == 0 && m0 + row < p.M) *(float2*)(p.rowstat_out + ((long long)(m0 + row) * p.tiles_n + n0 / BN) * 2) = make_float2(a, q);
+    }
+    if constexpr (!GEGLU) {
+        if (p.gn_part) {
+            // first GroupNorm pass of the ROUNDED output (idb_gemm_desc.gn_partials: [batch][HW / 64][groups] {sum, sum of squares}),
+            // behind the stores like the row statistics: the tile holds BM / 64 row chunks x BN / cpg whole groups = 4-32 items of
+            // 64 x cpg values; TPI lanes of ONE wave per item, each summing rows sub, sub + TPI, ... as dword pairs (cpg is even),
+            // fixed order + shuffle tree: deterministic, no atomics.  The host guarantees M % 64 == 0 and N % BN == 0.
+            const int cpg = p.N / p.gn_groups, gpt = BN / cpg, items = (BM / 64) * gpt;
+            int tpi = THREADS / items;
+            if (tpi > 64) tpi = 64;
+            const int item = tid / tpi, sub = tid - item * tpi;
+            if (item < items) {
+                const int c = item / gpt, g = item - c * gpt;
+                const char* base = smem + (c * 64) * OLD + g * cpg * 2;
+                const bool live = m0 + c * 64 < p.M;
+                float a = 0.f, q = 0.f;
+                for (int r = sub; r < 64 && live; r += tpi) {
+                    const unsigned* rp = (const unsigned*)(base + r * OLD);
+                    for (int k = 0; k < cpg / 2; ++k) {
+                        const unsigned w2 = rp[k];
+                        const float f0 = to_f32<T>(__builtin_bit_cast(T, (unsigned short)(w2 & 0xffffu)));
+                        const float f1 = to_f32<T>(__builtin_bit_cast(T, (unsigned short)(w2 >> 16)));
+                        a += f0 + f1;
+                        q += f0 * f0 + f1 * f1;
+                    }
+                }
+                for (int o = 1; o < tpi; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                if (sub == 0 && live) {
+                    const int mrow = m0 + c * 64, b = mrow / p.HW, chunk = (mrow - b * p.HW) >> 6;
+                    float* dst = p.gn_part + (((long long)b * (p.HW >> 6) + chunk) * p.gn_groups + n0 / cpg + g) * 2;
+                    dst[0] = a;
+                    dst[1] = q;
+                }
+            }
+        }
     }
 }
 
@@ -623,11 +665,22 @@ inline bool idb_reduce_vec_ok(const GemmParams& p, int n) {
            ((uintptr_t)p.out & 15) == 0;
 }
 
+// Can the LDS-staged epilogue of a bm x bn tile emit the first GroupNorm pass of an [M][n] output itself (GemmParams::gn_part)?
+// Whole groups per column tile, whole 64-row chunks per row tile, an even group width (dword pairs), at most 64 lanes per item.
+inline bool idb_epilogue_emits_gn(int bm, int bn, int threads, long long M, int n, int groups) {
+    if (groups <= 0 || n % groups || n % bn || bm % 64 || M % 64) return false;
+    const int cpg = n / groups;
+    if (cpg % 2 || bn % cpg) return false;
+    const int items = (bm / 64) * (bn / cpg);
+    return items <= threads && threads % items == 0 && ((threads / items) & (threads / items - 1)) == 0;
+}
+
 // Split-K reduce launch (+ the GroupNorm statistics of the output when asked for: from the reduce launch when the slabs were
-// written in its window order, by an extra statistics launch otherwise).
+// written in its window order, from the GEMM's own LDS-staged epilogue when there is no split (p.gn_part), by an extra statistics
+// launch otherwise).
 template <typename T>
 int idb_finish_splitk(const GemmParams& p, int M, int n, int batch, int splitk, float* gn_partials, int gn_groups, int dtype, hipStream_t st) {
-    if (gn_partials && (splitk == 1 || p.counters))
+    if (gn_partials && !p.gn_part && (splitk == 1 || p.counters))
         return idb_launch_gn_stats64(p.out, n, batch, p.HW, gn_groups, gn_partials, dtype, st);   // no reduce launch to ride on
     if (splitk == 1 || p.counters) return IDB_OK;
     if (p.slab_swc) {

@@ -128,6 +128,7 @@ class HipEngine:
         # rstd / mean correction in the consumer's; IDB_LN_FOLD=0 keeps the idb_layernorm launches
         self._ln_fold = os.environ.get("IDB_LN_FOLD", "1") != "0"
         self._fold_cache: Dict[Tuple[int, int, int, bool], bool] = {}
+        self._gn_epi = os.environ.get("IDB_GN_EPILOGUE", "1") != "0"      # GroupNorm statistics from non-split GEMM epilogues
         self._use_hconv = os.environ.get("IDB_HCONV", "0") == "1"
         self._hconv_tiles = int(os.environ.get("IDB_HCONV_TILES", "512"))
         self._hconv_proj_in = os.environ.get("IDB_HCONV_PROJ_IN", "1") != "0"      # Transformer2DModel.norm + proj_in fused as well
@@ -458,9 +459,10 @@ class HipEngine:
         if gn_stats and self._gn_fuse and (oh * ow) % 64 == 0 and oh * ow <= 4096 and not geglu and not out_f32 and n % gn_stats == 0:
             # the GroupNorm that consumes `out` next gets its first pass from this GEMM's split-K reduce launch (idb_kernels.h);
             # without a split there is no launch to ride on and the ordinary two-pass GroupNorm is at least as good
-            ptile, psk, pblocks = C.c_int32(), C.c_int32(), C.c_int32()
-            L.check(self.lib.idb_gemm_plan(C.byref(d), C.byref(ptile), C.byref(psk), C.byref(pblocks)), "idb_gemm_plan")
-            if psk.value > 1 or gn_stats_always:      # gn_stats_always: tests of the library's extra-statistics-launch path
+            mode = self.lib.idb_gemm_emits_gn_partials(C.byref(d), gn_stats)     # 1: split-K reduce launch, 2: the GEMM's own epilogue
+            if mode == 2 and not self._gn_epi:
+                mode = 0
+            if mode > 0 or gn_stats_always:      # gn_stats_always: tests of the library's extra-statistics-launch path
                 gn_part = self.arena.alloc((batch * (oh * ow // 64) * gn_stats * 2,), torch.float32)
                 d.gn_partials, d.gn_groups = gn_part.data_ptr(), gn_stats
         d.counters, d.counters_len = self._counters.data_ptr(), self._counters.numel()
@@ -771,7 +773,7 @@ class HipEngine:
         self.arena.free(n2)
         return out
 
-    def _transformer(self, a: S.AttnSpec, x, batch, h, w_, kv, n_ctx) -> torch.Tensor:
+    def _transformer(self, a: S.AttnSpec, x, batch, h, w_, kv, n_ctx, out_stats: bool = False) -> torch.Tensor:
         W, n, c = self.w, a.name, a.channels
         hw = h * w_
         m = batch * hw
@@ -809,7 +811,9 @@ class HipEngine:
         h3 = self.linear(gg, W[f"{n}.ff2.w"], c, 4 * c, bias=W[f"{n}.ff2.b"], residual=h2)
         self.arena.free(gg)
         self.arena.free(h2)
-        out = self.linear(h3, W[f"{n}.proj_out.w"], c, c, bias=W[f"{n}.proj_out.b"], residual=x)
+        # out_stats: the next consumer is a non-concatenated GroupNorm (a resnet's norm1, conv_norm_out)
+        out = self.gemm([(h3, c, 1, h, w_, 0)], W[f"{n}.proj_out.w"], c, batch, h, w_, bias=W[f"{n}.proj_out.b"], residual=x,
+                        gn_stats=G if out_stats else 0)
         self.arena.free(h3)
         return out
 
@@ -870,7 +874,7 @@ class HipEngine:
                 self._free(x)
                 x, ch = self._tap(r.name, y), r.cout
                 if blk["attns"]:
-                    y = self._transformer(blk["attns"][j], x, B, h, w_, kv[blk["attns"][j].name], n_ctx)
+                    y = self._transformer(blk["attns"][j], x, B, h, w_, kv[blk["attns"][j].name], n_ctx, out_stats=not (last and blk["down"]))
                     self._free(x)
                     x = self._tap(blk["attns"][j].name, y)
                 skips.append((x, ch))
@@ -885,13 +889,13 @@ class HipEngine:
         m = g.mid
         y = self._resnet(m["resnets"][0].name, x, ch, None, 0, ch, B, h, w_, sbias, eps_n, out_stats=True)
         x = self._tap(m["resnets"][0].name, y)          # previous x is the last skip: stays pinned
-        y = self._transformer(m["attn"], x, B, h, w_, kv[m["attn"].name], n_ctx)
+        y = self._transformer(m["attn"], x, B, h, w_, kv[m["attn"].name], n_ctx, out_stats=True)
         self._free(x)
         x = self._tap(m["attn"].name, y)
         y = self._resnet(m["resnets"][1].name, x, ch, None, 0, ch, B, h, w_, sbias, eps_n)
         self._free(x)
         x = self._tap(m["resnets"][1].name, y)
-        for blk in g.up:
+        for bi, blk in enumerate(g.up):
             for j, r in enumerate(blk["resnets"]):
                 sk, sc = skips.pop()
                 assert sc == r.skip_channels and ch + sc == r.cin
@@ -901,7 +905,8 @@ class HipEngine:
                 self._free(x)
                 x, ch = self._tap(r.name, y), r.cout
                 if blk["attns"]:
-                    y = self._transformer(blk["attns"][j], x, B, h, w_, kv[blk["attns"][j].name], n_ctx)
+                    final = bi == len(g.up) - 1 and j == len(blk["resnets"]) - 1 and not blk["up"]     # next: conv_norm_out
+                    y = self._transformer(blk["attns"][j], x, B, h, w_, kv[blk["attns"][j].name], n_ctx, out_stats=final)
                     self._free(x)
                     x = self._tap(blk["attns"][j].name, y)
             if blk["up"]:

@@ -93,7 +93,8 @@ typedef struct {
     int32_t counters_len;
     float* gn_partials;       /* optional out: per-(sample, 64-row block, group) {sum, sum of squares} of the ROUNDED output, fp32
                                  [batch][out_h*out_w/64][gn_groups][2] — the first pass of the nn.GroupNorm that consumes `out`
-                                 (idb_groupnorm's partials_in), produced by the split-K reduce launch when there is one, by an extra
+                                 (idb_groupnorm's partials_in), produced by the split-K reduce launch when there is one, by the GEMM's own
+                                 LDS-staged epilogue when its column tiles hold whole groups (idb_gemm_emits_gn_partials), by an extra
                                  statistics launch otherwise.  Needs out_h*out_w % 64 == 0, out_h*out_w <= 4096, n % gn_groups == 0,
                                  operand-dtype output, no GEGLU */
     int32_t gn_groups;
@@ -124,6 +125,10 @@ size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);
 int idb_gemm_plan(const idb_gemm_desc* d, int32_t* tile, int32_t* split_k, int32_t* blocks);
 /* Column tiles of the plan idb_gemm would run for `d` if that plan can emit row statistics (LDS-staged epilogue), else 0. */
 int32_t idb_gemm_row_stats_tiles(const idb_gemm_desc* d);
+/* Would idb_gemm produce gn_partials for `groups` groups WITHOUT an extra statistics launch?  0: no (it would launch one — the caller's
+ * two-pass idb_groupnorm is as good); 1: from its split-K reduce launch; 2: from its own LDS-staged epilogue (no split-K, 160-wide
+ * tiles holding whole groups). */
+int32_t idb_gemm_emits_gn_partials(const idb_gemm_desc* d, int32_t groups);
 /* 1 if the plan idb_gemm would run for `d` (bias / sample_bias NULL, one 1x1 source) can apply a folded LayerNorm (ln_*). */
 int32_t idb_gemm_folds_layernorm(const idb_gemm_desc* d);
 int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);

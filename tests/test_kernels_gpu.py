@@ -226,7 +226,10 @@ def test_groupnorm(eng, b, hw, c0, c1, silu, eps):
 
 
 @pytest.mark.parametrize("b,side,cin,cout,split_k,res", [(2, 16, 128, 320, 4, True), (2, 32, 64, 640, 8, False), (1, 8, 256, 1280, 16, True),
-                                                         (2, 16, 128, 320, 1, True), (3, 8, 64, 128, 3, False), (2, 64, 64, 320, 2, False)])
+                                                         (2, 16, 128, 320, 1, True), (3, 8, 64, 128, 3, False), (2, 64, 64, 320, 2, False),
+                                                         # no split, 160-wide tiles: the GEMM's own epilogue emits them (cpg 10 / 20 / 40; 128- and 64-row tiles)
+                                                         (8, 64, 64, 320, 1, True), (8, 32, 64, 640, 1, False), (16, 16, 128, 1280, 1, True),
+                                                         (1, 64, 64, 320, 1, False), (5, 8, 64, 320, 1, True)])
 def test_groupnorm_statistics_from_the_gemm(eng, b, side, cin, cout, split_k, res):
     """idb_gemm_desc.gn_partials: the conv's split-K reduce launch (or, without a split, an extra statistics launch) emits the
     per-(sample, 64-row block, group) sums of its rounded output; idb_groupnorm(partials_in) then only normalises.  The result
@@ -242,12 +245,17 @@ def test_groupnorm_statistics_from_the_gemm(eng, b, side, cin, cout, split_k, re
     wp = eng._pack_conv(w)
     eng.arena.reset()
     y = eng.gemm([(x, cin, 9, side, side, 0)], wp, cout, b, side, side, bias=bias, residual=resid, split_k=split_k, gn_stats=32)
-    if split_k == 1:                     # no reduce launch to ride on: the engine does not ask; the library would add a launch
-        assert getattr(y, "_gn", None) is None
+    if split_k == 1 and getattr(y, "_gn", None) is None:   # neither a reduce launch nor a 160-wide LDS-staged epilogue: the engine does not ask
         eng.arena.free(y)
         y = eng.gemm([(x, cin, 9, side, side, 0)], wp, cout, b, side, side, bias=bias, residual=resid, split_k=1, gn_stats=32,
                      gn_stats_always=True)
     assert getattr(y, "_gn", None) is not None and y._gn[1] == hw // 64
+    torch.cuda.synchronize()
+    cpg = cout // 32                     # the partials themselves: {sum, sum of squares} of the ROUNDED output per (sample, 64 rows, group)
+    yr = y.double().view(b, hw // 64, 64, 32, cpg)
+    part = y._gn[0].view(b, hw // 64, 32, 2).double()
+    assert torch.allclose(part[..., 0], yr.sum(dim=(2, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[..., 1], (yr * yr).sum(dim=(2, 4)), rtol=1e-5, atol=1e-3)
     y_plain = eng.gemm([(x, cin, 9, side, side, 0)], wp, cout, b, side, side, bias=bias, residual=resid, split_k=split_k)
     fused = eng.groupnorm(y, cout, None, 0, b, hw, gamma, beta, 1e-5, True, groups=32)
     assert y._gn is None
@@ -466,3 +474,26 @@ def test_lora_merge_and_pack(eng):
     packed = eng._pack_conv(cw)
     torch.cuda.synchronize()
     assert torch.equal(packed, cw.permute(0, 2, 3, 1).reshape(8, -1).to(eng.tdt))
+
+
+def test_gemm_epilogue_emits_groupnorm_partials_only_for_whole_groups(eng):
+    """idb_gemm_emits_gn_partials: 2 = from the LDS-staged epilogue (no split, 160-wide tile, whole groups per column tile),
+    1 = from the split-K reduce launch, 0 = it would take an extra launch (128-wide tiles cut groups of 10 / 20 / 40 channels)."""
+    import ctypes as C
+    from faceposegenerator_amd import _lib as L
+    x = torch.zeros(64, device=DEV)
+
+    def mode(m_hw, batch, cin, taps, n, tile=0):
+        d = L.GemmDesc()
+        side = int(m_hw ** 0.5)
+        d.dtype, d.batch, d.out_h, d.out_w, d.stride, d.n, d.nsrc = eng.dt, batch, side, side, 1, n, 1
+        d.src[0].ptr, d.src[0].channels, d.src[0].taps, d.src[0].in_h, d.src[0].in_w = x.data_ptr(), cin, taps, side, side
+        d.w, d.out, d.out_dtype, d.out_ld, d.tile = x.data_ptr(), x.data_ptr(), eng.dt, n, tile
+        return eng.lib.idb_gemm_emits_gn_partials(C.byref(d), 32)
+
+    assert mode(4096, 128, 320, 9, 320) == 2          # batch-64 conv: 128x160, no split
+    assert mode(4096, 128, 320, 1, 320) == 2          # proj_out
+    assert mode(4096, 2, 320, 9, 320) == 2            # the same conv at batch 1: 64x160 tiles, still no split
+    assert mode(256, 2, 1280, 9, 1280) == 1           # batch-1 conv at 16x16: split-K, statistics from the reduce launch
+    assert mode(4096, 128, 320, 9, 320, tile=9) == 0  # 128x128 tiles cut the groups
+    assert mode(4096, 128, 320, 9, 336) == 0          # 336 / 32 is not an integer group width
