@@ -69,7 +69,7 @@ class GemmFp8Desc(C.Structure):
                 ("n", C.c_int32), ("x", C.c_void_p), ("channels", C.c_int32), ("taps", C.c_int32), ("in_h", C.c_int32),
                 ("in_w", C.c_int32), ("upsample", C.c_int32), ("x_scale", C.c_float), ("w", C.c_void_p), ("w_scale", C.c_void_p),
                 ("bias", C.c_void_p), ("sample_bias", C.c_void_p), ("sample_bias_ld", C.c_int32), ("residual", C.c_void_p),
-                ("out", C.c_void_p), ("out_ld", C.c_int32)]
+                ("out", C.c_void_p), ("out_ld", C.c_int32), ("gn_partials", C.c_void_p), ("gn_groups", C.c_int32)]
 
 
 class IdbError(RuntimeError):

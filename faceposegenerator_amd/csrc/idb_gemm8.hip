@@ -307,6 +307,20 @@ extern "C" int idb_gemm_fp8(const idb_gemm_fp8_desc* d, void* stream) {
     g.tiles_n = (d->n + 32 * nf - 1) / (32 * nf);
     const int tiles = (int)((M + 127) / 128) * g.tiles_n;
     hipStream_t st = (hipStream_t)stream;
-    if (d->out_dtype == IDB_BF16) return nf == 5 ? launch_gemm8<__bf16, 2, 5, 2>(p, tiles, st) : launch_gemm8<__bf16, 2, 4, 2>(p, tiles, st);
-    return nf == 5 ? launch_gemm8<_Float16, 2, 5, 2>(p, tiles, st) : launch_gemm8<_Float16, 2, 4, 2>(p, tiles, st);
+    bool gn_after = false;                 // first GroupNorm pass of the output: from the shared LDS-staged epilogue when it can
+    if (d->gn_partials) {
+        IDB_REQUIRE(d->gn_groups > 0 && d->n % d->gn_groups == 0 && g.HW % 64 == 0 && g.HW <= 4096 && d->out_ld == d->n && idb_aligned16(d->gn_partials),
+                    "idb_gemm_fp8: gn_partials needs n %% gn_groups == 0, out_h*out_w %% 64 == 0 and <= 4096, dense output");
+        if (idb_epilogue_emits_gn(128, 32 * nf, 512, M, d->n, d->gn_groups)) {
+            g.gn_part = d->gn_partials;
+            g.gn_groups = d->gn_groups;
+        } else {
+            gn_after = true;
+        }
+    }
+    int rc;
+    if (d->out_dtype == IDB_BF16) rc = nf == 5 ? launch_gemm8<__bf16, 2, 5, 2>(p, tiles, st) : launch_gemm8<__bf16, 2, 4, 2>(p, tiles, st);
+    else rc = nf == 5 ? launch_gemm8<_Float16, 2, 5, 2>(p, tiles, st) : launch_gemm8<_Float16, 2, 4, 2>(p, tiles, st);
+    if (rc != IDB_OK || !gn_after) return rc;
+    return idb_launch_gn_stats64(d->out, d->n, d->batch, g.HW, d->gn_groups, d->gn_partials, d->out_dtype, st);
 }

@@ -632,7 +632,9 @@ class HipEngine:
 
     def gemm_fp8(self, x8: torch.Tensor, x_scale: float, channels: int, taps: int, in_h: int, in_w: int, w8: torch.Tensor, w_scale: torch.Tensor,
                  n: int, batch: int, oh: int, ow: int, bias=None, sbias=None, residual=None, stride: int = 1, upsample: int = 0,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, gn_stats: int = 0) -> torch.Tensor:
+        """gn_stats = G: also the first pass of the GroupNorm(G) that reads ``out`` next (``out._gn``), when the kernel's own epilogue can
+        emit it (160-wide tiles holding whole groups; idb_gemm_fp8 would add a launch otherwise, no better than the two-pass GroupNorm)."""
         m = batch * oh * ow
         if out is None:
             out = self.arena.alloc((m, n), self.tdt)
@@ -644,7 +646,14 @@ class HipEngine:
             d.sample_bias = sbias[0].data_ptr() + 4 * sbias[1]
             d.sample_bias_ld = sbias[2]
         d.residual, d.out, d.out_ld = _ptr(residual), out.data_ptr(), out.shape[-1]
+        gn_part = None
+        if gn_stats and self._gn_fuse and self._gn_epi and n % 160 == 0 and n % gn_stats == 0 and 160 % (n // gn_stats) == 0 and \
+                (n // gn_stats) % 2 == 0 and (oh * ow) % 64 == 0 and oh * ow <= 4096 and out.shape[-1] == n:
+            gn_part = self.arena.alloc((batch * (oh * ow // 64) * gn_stats * 2,), torch.float32)
+            d.gn_partials, d.gn_groups = gn_part.data_ptr(), gn_stats
         L.check(self.lib.idb_gemm_fp8(C.byref(d), _stream()), "idb_gemm_fp8")
+        if gn_part is not None:
+            out._gn = (gn_part, oh * ow // 64, gn_stats)
         return out
 
     def layernorm(self, x, rows, c, gamma, beta) -> torch.Tensor:
@@ -738,7 +747,7 @@ class HipEngine:
             sb = None if sbias is None else (sbias[0], sbias[1] + self.tproj_off[name], sbias[2])
             n1 = self.groupnorm_fp8(xa, ca, xb, cb, batch, h * w_, W[f"{name}.gn1.g"], W[f"{name}.gn1.b"], eps, True, groups)
             h1 = self.gemm_fp8(n1, self.X8_SCALE, cin, 9, h, w_, W[f"{name}.conv1.w8"], W[f"{name}.conv1.s8"], cout, batch, h, w_,
-                               bias=W[f"{name}.conv1.b"], sbias=sb)
+                               bias=W[f"{name}.conv1.b"], sbias=sb, gn_stats=G0)
             self.arena.free(n1)
             n2 = self.groupnorm_fp8(h1, cout, None, 0, batch, h * w_, W[f"{name}.gn2.g"], W[f"{name}.gn2.b"], eps, True, groups)
             self.arena.free(h1)
@@ -748,7 +757,7 @@ class HipEngine:
             else:
                 res = xa
             out = self.gemm_fp8(n2, self.X8_SCALE, cout, 9, h, w_, W[f"{name}.conv2.w8"], W[f"{name}.conv2.s8"], cout, batch, h, w_,
-                                bias=W[f"{name}.conv2.b"], residual=res)
+                                bias=W[f"{name}.conv2.b"], residual=res, gn_stats=G0 if out_stats else 0)
             self.arena.free(n2)
             if short:
                 self.arena.free(res)

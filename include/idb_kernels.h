@@ -335,6 +335,10 @@ typedef struct {
     const void* residual;
     void* out;
     int32_t out_ld;
+    float* gn_partials;           /* optional out, as idb_gemm_desc.gn_partials: written by the kernel's own epilogue when the column tiles
+                                     hold whole groups (n % 160 == 0, 160 % (n / gn_groups) == 0, out_h*out_w % 64 == 0, out_ld == n),
+                                     else by an extra statistics launch */
+    int32_t gn_groups;
 } idb_gemm_fp8_desc;
 int idb_quantize_fp8(const void* x, void* out, int64_t count, float inv_scale, int32_t dtype, void* stream);
 /* idb_groupnorm (two-launch form) writing its output as fp8 e4m3 of y * out_inv_scale, saturating: the activation operand of

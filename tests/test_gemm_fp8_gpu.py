@@ -72,3 +72,26 @@ def test_gemm_fp8_conv_and_linear(eng, b, h, w_, cin, cout, taps, stride, up):
                     padding=1 if taps == 9 else 0) + sb[:, :, None, None] + res.float()
     rel = ((got - full).norm() / full.norm()).item()
     assert rel < 6e-2, rel
+
+
+@pytest.mark.parametrize("b,side,cin,cout", [(2, 32, 320, 320), (3, 16, 128, 640), (1, 8, 256, 1280)])
+def test_gemm_fp8_emits_groupnorm_partials(eng, b, side, cin, cout):
+    """idb_gemm_fp8_desc.gn_partials from the kernel's own LDS-staged epilogue (160-wide tiles, groups of 10 / 20 / 40 channels):
+    {sum, sum of squares} of the ROUNDED output per (sample, 64-row chunk, group), and the same output tensor as without them."""
+    x = _rand((b, side, side, cin), 20, 2.0).to(eng.tdt)
+    wt = _rand((cout, cin, 3, 3), 21, (9 * cin) ** -0.5)
+    bias = _rand((cout,), 22)
+    x_scale = float(x.float().abs().max()) / 448.0
+    x8 = eng.quantize_fp8(x, x_scale)
+    w8, ws = eng.pack_weight_fp8(wt)
+    plain = eng.gemm_fp8(x8, x_scale, cin, 9, side, side, w8, ws, cout, b, side, side, bias=bias)
+    out = eng.gemm_fp8(x8, x_scale, cin, 9, side, side, w8, ws, cout, b, side, side, bias=bias, gn_stats=32)
+    st = getattr(out, "_gn", None)
+    assert st is not None and st[1] == side * side // 64
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain)
+    cpg, hw = cout // 32, side * side
+    yr = out.double().view(b, hw // 64, 64, 32, cpg)
+    part = st[0].view(b, hw // 64, 32, 2).double()
+    assert torch.allclose(part[..., 0], yr.sum(dim=(2, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[..., 1], (yr * yr).sum(dim=(2, 4)), rtol=1e-5, atol=1e-3)
