@@ -420,6 +420,24 @@ def test_conv_in(eng):
     _check(out[: b * h * w_].view(b, h, w_, cout).permute(0, 3, 1, 2), ref, _tol(eng, 4.0), "conv_in + post_quant")
 
 
+@pytest.mark.parametrize("b,h,w_,cout,rep,scale", [(4, 64, 64, 320, 2, 1.0), (2, 128, 64, 320, 1, 0.5), (3, 96, 96, 128, 2, 1.0), (4, 64, 65, 64, 1, 1.0)])
+def test_conv_in_lds_form(eng, b, h, w_, cout, rep, scale):
+    """>= 16,384 pixels, even width: weights in LDS, 2 pixels x 8 channels per thread (idb_misc.hip conv_in_lds_kernel); the odd-width
+    case stays on the first kernel.  Same fp32 arithmetic: same tolerance, CFG copies identical."""
+    from faceposegenerator_amd import _lib as L
+    x = _rand((b, 4, h, w_), 95, 3.0)
+    w, bias = _rand((cout, 4, 3, 3), 96, 1 / 6.0), _rand((cout,), 97)
+    out = torch.full((rep * b * h * w_, cout), float("nan"), dtype=eng.tdt, device=DEV)
+    L.check(eng.lib.idb_conv_in(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), b, rep, 4, h, w_, cout, scale, None, None,
+                                eng.dt, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x * scale, w, bias, padding=1)
+    got = out.view(rep, b, h, w_, cout).permute(0, 1, 4, 2, 3)
+    _check(got[0], ref, _tol(eng), "conv_in (LDS form)")
+    for r in range(1, rep):
+        assert torch.equal(got[0], got[r])
+
+
 def test_cfg_ddpm_step_and_scheduler(eng):
     from faceposegenerator_amd.scheduler import DDPMScheduler
     from oracle import sd21_oracle as O
