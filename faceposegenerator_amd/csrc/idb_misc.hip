@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
                 float v = 0.f;
                 if (ok && ci < cin) {
                     v = pre_b[ci];
-                    for (int cj = 0; cj < cin; ++cj) v += pre_w[ci * cin + cj] * raw[cj];
+#pragma unroll
+                    for (int cj = 0; cj < 4; ++cj)
+                        if (cj < cin) v += pre_w[ci * cin + cj] * raw[cj];
                 }
                 in[tap][ci] = v;
             }
@@ -148,9 +150,14 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
         const int co = co0 + e;
         float a = co < cout ? bias[co] : 0.f;
         if (co < cout) {
-            for (int ci = 0; ci < cin; ++ci)
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) a += w[((long long)co * cin + ci) * 9 + tap] * in[tap][ci];
+            for (int ci = 0; ci < 4; ++ci)          // static indices: a `ci < cin` loop bound put in[][] into scratch (160 B per lane): 1.41 ms
+                                                    // per launch at B = 64 (batch 64 15.05 -> 15.17 images/s without it; an LDS-weight, 2-pixel
+                                                    // form with contiguous stores was measured no faster than this fix and is not kept)
+                if (ci < cin) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) a += w[((long long)co * cin + ci) * 9 + tap] * in[tap][ci];
+                }
         }
         acc[e] = a;
     }
@@ -160,80 +167,6 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     for (int r = 0; r < rep; ++r) {
         T* dst = out + (((long long)r * batch + b) * HW + rem) * cout + co0;
         *(typename Op<T>::v8*)dst = o;
-    }
-}
-
-// UNet conv_in at scale (cin = 4, no pre-conv, even width): the first form writes 16-byte pieces at a 2*cout-byte stride (one
-// pixel per lane) and re-gathers the 36 inputs once per 8-channel block row (cout / 8 = 40 times) — 1.41 ms at B = 64, 8.5 TFLOP/s.
-// Here the weights sit transposed in LDS ([36][cout] fp32), a thread owns 2 horizontally adjacent pixels x 8 output channels (one
-// 16-byte LDS read pair feeds 16 FMAs: VALU-bound, not LDS-bound) and the channel chunk runs fastest across lanes, so a wave's
-// stores are contiguous runs of the NHWC rows.  Same fp32 arithmetic, one rounding.
-template <typename T>
-__global__ __launch_bounds__(256) void conv_in_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, T* __restrict__ out, int batch, int rep,
-                                                          int H, int W, int cout, float in_scale, int iters) {
-    extern __shared__ float wT[];                                 // [36][cout]
-    for (int i = threadIdx.x; i < 36 * cout; i += 256) {
-        const int k = i / cout, co = i - k * cout;
-        wT[i] = w[co * 36 + k];                                   // w is [cout][4][3][3]
-    }
-    __syncthreads();
-    const int chunks = cout >> 3, W2 = W >> 1;
-    const long long HW = (long long)H * W;
-    const long long items = (long long)batch * H * W2 * chunks;
-    long long item = ((long long)blockIdx.x * iters) * 256 + threadIdx.x;
-    for (int it = 0; it < iters && item < items; ++it, item += 256) {
-        const int chunk = (int)(item % chunks);
-        const long long pair = item / chunks;
-        const int px = (int)(pair % W2);
-        const long long rowi = pair / W2;
-        const int oy = (int)(rowi % H), b = (int)(rowi / H);
-        const int x0 = px * 2;
-        float win[4][3][4];                                       // [ci][row oy-1..oy+1][col x0-1..x0+2]
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int iy = oy + r - 1, ix = x0 + c - 1;
-                    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                    win[ci][r][c] = ok ? x[((long long)b * 4 + ci) * HW + (long long)iy * W + ix] * in_scale : 0.f;
-                }
-        const f32x4 b0 = *(const f32x4*)(bias + chunk * 8), b1 = *(const f32x4*)(bias + chunk * 8 + 4);
-        float a0[8], a1[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a0[e] = a1[e] = b0[e];
-            a0[4 + e] = a1[4 + e] = b1[e];
-        }
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float* wp = wT + (ci * 9 + tap) * cout + chunk * 8;
-                const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
-                const float i0 = win[ci][tap / 3][tap % 3], i1 = win[ci][tap / 3][tap % 3 + 1];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a0[e] += w0[e] * i0;
-                    a0[4 + e] += w1[e] * i0;
-                    a1[e] += w0[e] * i1;
-                    a1[4 + e] += w1[e] * i1;
-                }
-            }
-        typename Op<T>::v8 o0, o1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            o0[e] = from_f32<T>(a0[e]);
-            o1[e] = from_f32<T>(a1[e]);
-        }
-        const long long pix = (long long)oy * W + x0;
-        for (int r = 0; r < rep; ++r) {
-            T* dst = out + (((long long)r * batch + b) * HW + pix) * cout + chunk * 8;
-            *(typename Op<T>::v8*)dst = o0;
-            *(typename Op<T>::v8*)(dst + cout) = o1;
-        }
     }
 }
 
@@ -437,22 +370,6 @@ extern "C" int idb_conv_in(const float* x_nchw, const float* w, const float* bia
                 "idb_conv_in: unsupported dims (cin<=4, cout%%8==0)");
     IDB_REQUIRE((pre_w == nullptr) == (pre_b == nullptr), "idb_conv_in: pre_w/pre_b must both be given");
     hipStream_t st = (hipStream_t)stream;
-    static const int env_v2 = [] { const char* e = getenv("IDB_CONV_IN_LDS"); return e ? atoi(e) : 16384; }();   // from this many pixels on (0: never): batch 64 15.05 -> 15.23 images/s; at 4,096 pixels (batch 1) the first form is no slower
-    if (!pre_w && cin == 4 && w_ % 2 == 0 && 36 * cout * 4 <= 64 * 1024 && idb_aligned16(bias) && env_v2 > 0 &&
-        (long long)batch * h * w_ >= env_v2) {
-        const long long items = (long long)batch * h * (w_ / 2) * (cout / 8);
-        int iters = (int)(items / (256LL * 2048));                // aim at >= 2048 workgroups, at most 16 items per thread
-        iters = iters < 1 ? 1 : (iters > 16 ? 16 : iters);
-        const unsigned nb = (unsigned)((items + 256LL * iters - 1) / (256LL * iters));
-        const size_t lds = (size_t)36 * cout * 4;
-        DISPATCH_T(dtype,
-                   hipLaunchKernelGGL((conv_in_lds_kernel<__bf16>), dim3(nb), dim3(256), lds, st, x_nchw, w, bias, (__bf16*)out, batch, rep, h, w_,
-                                      cout, in_scale, iters),
-                   hipLaunchKernelGGL((conv_in_lds_kernel<_Float16>), dim3(nb), dim3(256), lds, st, x_nchw, w, bias, (_Float16*)out, batch, rep, h,
-                                      w_, cout, in_scale, iters));
-        IDB_CHECK_LAUNCH("idb_conv_in(lds)");
-        return IDB_OK;
-    }
     dim3 grid(blocks_for((long long)batch * h * w_), cout / 8);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((conv_in_kernel<__bf16>), grid, dim3(256), 0, st, x_nchw, w, bias, (__bf16*)out, batch, rep,

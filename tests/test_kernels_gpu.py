@@ -421,9 +421,8 @@ def test_conv_in(eng):
 
 
 @pytest.mark.parametrize("b,h,w_,cout,rep,scale", [(4, 64, 64, 320, 2, 1.0), (2, 128, 64, 320, 1, 0.5), (3, 96, 96, 128, 2, 1.0), (4, 64, 65, 64, 1, 1.0)])
-def test_conv_in_lds_form(eng, b, h, w_, cout, rep, scale):
-    """>= 16,384 pixels, even width: weights in LDS, 2 pixels x 8 channels per thread (idb_misc.hip conv_in_lds_kernel); the odd-width
-    case stays on the first kernel.  Same fp32 arithmetic: same tolerance, CFG copies identical."""
+def test_conv_in_large(eng, b, h, w_, cout, rep, scale):
+    """conv_in at the sizes of the large-batch runs (full 320 channels, CFG duplication, input scale, odd width)."""
     from faceposegenerator_amd import _lib as L
     x = _rand((b, 4, h, w_), 95, 3.0)
     w, bias = _rand((cout, 4, 3, 3), 96, 1 / 6.0), _rand((cout,), 97)
@@ -433,7 +432,7 @@ def test_conv_in_lds_form(eng, b, h, w_, cout, rep, scale):
     torch.cuda.synchronize()
     ref = F.conv2d(x * scale, w, bias, padding=1)
     got = out.view(rep, b, h, w_, cout).permute(0, 1, 4, 2, 3)
-    _check(got[0], ref, _tol(eng), "conv_in (LDS form)")
+    _check(got[0], ref, _tol(eng), "conv_in (large)")
     for r in range(1, rep):
         assert torch.equal(got[0], got[r])
 
