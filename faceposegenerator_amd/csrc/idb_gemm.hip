@@ -727,6 +727,9 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         if (d->n <= 32) tile = 5;
         else if (d->geglu && blocks_big >= 256) tile = pl->ktiles >= 16 ? 2 : 9;   // N = 8C, no split-K: 128-row (persistent form for K >= 1024)
         else if (blocks_big >= (plan_ab_early & 2 ? 512 : 384)) tile = n160 ? 8 : 9;   // measured at batch 3 (384 workgroups): +6 % over the 64-row tiles; at 256 (batch 2): -1.4 %
+        // (the 4-wave 128x160 tile reads 9 instead of 14 ds_read_b128 per 20 MFMAs and is 2-5 % faster on every long-K conv with
+        //  M >= 32,768 in tools/bench_conv.py at B_eff 128 — end to end it changed nothing: batch 64 15.39 vs 15.32-15.35, batch 8 / 16
+        //  -0.3 %; not adopted)
         else if (!d->geglu && pl->ktiles >= 32 && blocks_big <= (plan_ab_early & 4 ? 255 : 256)) {   // = 256 (batch 2, 64x64 level): 37.7 vs 49.8 us
             int sk = (int)(256 / blocks_big);
             const int cap = pl->ktiles / 8;
