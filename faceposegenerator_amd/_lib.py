@@ -27,7 +27,7 @@ EXPORTS = [
     "idb_timestep_sinusoid", "idb_linear_f32", "idb_conv_in",
     "idb_cfg_ddpm_step", "idb_postprocess",
     "idb_nhwc_to_nchw_f32", "idb_f32_nhwc_to_nchw", "idb_cast_f32", "idb_vae_sample", "idb_warp_affine_u8",
-    "idb_crop_resize_area_u8", "idb_conv2d_f32", "idb_maxpool2d_f32", "idb_softmax_pairs_f32",
+    "idb_crop_resize_area_u8", "idb_conv2d_f32", "idb_maxpool2d_f32", "idb_softmax_pairs_f32", "idb_nms_mask",
     "idb_quantize_fp8", "idb_pack_weight_fp8", "idb_gemm_fp8", "idb_groupnorm_fp8",
 ]
 
@@ -128,6 +128,7 @@ def load() -> C.CDLL:
         "idb_conv2d_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
         "idb_maxpool2d_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "idb_softmax_pairs_f32": (C.c_int, [vp, vp, i32, i32, vp]),
+        "idb_nms_mask": (C.c_int, [vp, vp, i32, C.c_float, i32, i32, vp, vp]),
         "idb_quantize_fp8": (C.c_int, [vp, vp, i64, f32, i32, vp]),
         "idb_pack_weight_fp8": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "idb_gemm_fp8": (C.c_int, [C.POINTER(GemmFp8Desc), vp]),

@@ -95,6 +95,44 @@ inline int pool_out(int n, int k, int s) {              // ceil_mode, padding 0 
     return o < 1 ? 1 : o;
 }
 
+// Suppression bit matrix of greedy NMS (facenet_pytorch detect_face.py: torchvision batched_nms "Union", nms_numpy "Min"): boxes come
+// sorted by descending score; bit j of mask[i][j / 64] says "box i, if kept, removes box j" (j > i, same image, overlap not <= thr:
+// a NaN overlap of two degenerate boxes removes, as `order = rest[o <= thr]` does on the host).  fp32 arithmetic in exactly the host
+// routine's operation order with contraction off (__f*_rn), so the host scan over these words keeps the same boxes as
+// mtcnn._nms.  One wave per 64 x 64 block, the column boxes through LDS.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ image, int n, float thr,
+                                                      int use_min, float one, unsigned long long* __restrict__ mask, int words) {
+    __shared__ float cb[64][5];
+    __shared__ int ci[64];
+    const int bw = blockIdx.x, bi = blockIdx.y, t = threadIdx.x;
+    const int i = bi * 64 + t, j0 = bw * 64;
+    if (bw < bi) {                                        // every column index is below every row index
+        if (i < n) mask[(long long)i * words + bw] = 0ull;
+        return;
+    }
+    const int jc = min(j0 + t, n - 1);
+    const float cx1 = boxes[jc * 4 + 0], cy1 = boxes[jc * 4 + 1], cx2 = boxes[jc * 4 + 2], cy2 = boxes[jc * 4 + 3];
+    cb[t][0] = cx1; cb[t][1] = cy1; cb[t][2] = cx2; cb[t][3] = cy2;
+    cb[t][4] = __fmul_rn(__fadd_rn(__fsub_rn(cx2, cx1), one), __fadd_rn(__fsub_rn(cy2, cy1), one));
+    ci[t] = image ? image[jc] : 0;
+    __syncthreads();
+    if (i >= n) return;
+    const float x1 = boxes[i * 4 + 0], y1 = boxes[i * 4 + 1], x2 = boxes[i * 4 + 2], y2 = boxes[i * 4 + 3];
+    const float area = __fmul_rn(__fadd_rn(__fsub_rn(x2, x1), one), __fadd_rn(__fsub_rn(y2, y1), one));
+    const int im = image ? image[i] : 0;
+    unsigned long long bits = 0ull;
+    for (int k = 0; k < 64; ++k) {
+        const int j = j0 + k;
+        if (j <= i || j >= n || ci[k] != im) continue;
+        const float w = fmaxf(0.f, __fadd_rn(__fsub_rn(fminf(x2, cb[k][2]), fmaxf(x1, cb[k][0])), one));
+        const float h = fmaxf(0.f, __fadd_rn(__fsub_rn(fminf(y2, cb[k][3]), fmaxf(y1, cb[k][1])), one));
+        const float inter = __fmul_rn(w, h);
+        const float o = use_min ? __fdiv_rn(inter, fminf(area, cb[k][4])) : __fdiv_rn(inter, __fsub_rn(__fadd_rn(area, cb[k][4]), inter));
+        if (!(o <= thr)) bits |= 1ull << k;
+    }
+    mask[(long long)i * words + bw] = bits;
+}
+
 }  // namespace
 
 extern "C" int idb_crop_resize_area_u8(const uint8_t* src, int32_t batch, int32_t h, int32_t w, int32_t channels, const int32_t* boxes,
@@ -136,5 +174,15 @@ extern "C" int idb_softmax_pairs_f32(const float* x, float* p1, int32_t batch, i
     const long long total = (long long)batch * hw;
     hipLaunchKernelGGL(softmax_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, p1, batch, hw);
     IDB_CHECK_LAUNCH("idb_softmax_pairs_f32");
+    return IDB_OK;
+}
+
+extern "C" int idb_nms_mask(const float* boxes, const int32_t* image, int32_t n, float thr, int32_t use_min, int32_t plus_one, uint64_t* mask,
+                            void* stream) {
+    IDB_REQUIRE(boxes && mask && n > 0 && n <= (1 << 20), "idb_nms_mask: bad arguments");
+    const int words = (n + 63) / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, (hipStream_t)stream, boxes, image, n, thr, use_min, plus_one ? 1.f : 0.f,
+                       (unsigned long long*)mask, words);
+    IDB_CHECK_LAUNCH("idb_nms_mask");
     return IDB_OK;
 }

@@ -304,6 +304,10 @@ int idb_warp_affine_u8(const uint8_t* src, int32_t batch, int32_t h, int32_t w, 
  *       (a kernel as large as the map)
  *   idb_maxpool2d_f32: nn.MaxPool2d(k, stride, ceil_mode=True) over `planes` = batch * channels maps
  *   idb_softmax_pairs_f32: softmax over a channel pair, p1 = softmax(x[b][0:2][i])[1]
+ *   idb_nms_mask: the suppression bit matrix of greedy NMS (torchvision.ops.batched_nms as detect_face.py calls it, use_min = 0, and
+ *       upstream's nms_numpy "Min" with +1 widths, use_min = 1 / plus_one = 1): boxes fp32 [n][4] SORTED by descending score, optional
+ *       image index int32 [n] (boxes of different images never suppress each other); mask uint64 [n][(n+63)/64], bit j of row i set
+ *       when box i would remove box j > i.  The greedy scan over the rows stays with the caller (host: a few hundred words).
  * ------------------------------------------------------------------------------------------ */
 int idb_crop_resize_area_u8(const uint8_t* src, int32_t batch, int32_t h, int32_t w, int32_t channels, const int32_t* boxes, int32_t n,
                             float* out, int32_t out_h, int32_t out_w, float sub, float mul, void* stream);
@@ -311,6 +315,8 @@ int idb_conv2d_f32(const float* x, const float* w, const float* bias, const floa
                    int32_t w_, int32_t cout, int32_t kh, int32_t kw, void* stream);
 int idb_maxpool2d_f32(const float* x, float* y, int32_t planes, int32_t h, int32_t w, int32_t k, int32_t stride, void* stream);
 int idb_softmax_pairs_f32(const float* x, float* p1, int32_t batch, int32_t hw, void* stream);
+int idb_nms_mask(const float* boxes, const int32_t* image, int32_t n, float thr, int32_t use_min, int32_t plus_one, uint64_t* mask,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) implicit GEMM on v_mfma_scale_f32_16x16x128_f8f6f4 — BASELINE configs[4] "fp8 MFMA weight path" (the 768x768

@@ -87,3 +87,27 @@ def test_detect_api_and_align_crop(det):
     lm = np.array([[70.0, 60.0], [120.0, 62.0], [95.0, 90.0], [75.0, 120.0], [118.0, 121.0]], dtype=np.float32)
     crop = FA.norm_crop(img[:1].to(DEV), lm[None])                  # landmarks in, 112x112 aligned crop out
     assert tuple(crop.shape) == (1, 112, 112, 3) and crop.dtype == torch.uint8
+
+
+@pytest.mark.parametrize("n,images,method,plus_one,thr", [(3000, 4, "Union", False, 0.5), (5000, 16, "Union", False, 0.7), (2500, 3, "Min", True, 0.7),
+                                                          (700, 1, "Union", False, 0.7), (64 * 9 + 1, 2, "Min", True, 0.5)])
+def test_device_nms_mask_keeps_exactly_the_host_routines_boxes(det, n, images, method, plus_one, thr):
+    """idb_nms_mask + the host scan (MTCNN._bnms) against the pure-numpy _batched_nms on crowded random boxes: identical indices in
+    identical order — score ties, duplicate boxes, zero-area boxes (NaN overlap under "Union" without +1) and boxes of different
+    images included."""
+    from faceposegenerator_amd import mtcnn as M
+    m, _ = det
+    rng = np.random.default_rng(n)
+    ctr = rng.uniform(0, 400, size=(n, 2))
+    wh = rng.uniform(4, 120, size=(n, 2))
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], axis=1).astype(np.float32)
+    boxes[::97] = boxes[1::97][: boxes[::97].shape[0]]                 # exact duplicates
+    boxes[5::211, 2:] = boxes[5::211, :2]                               # zero-area boxes
+    scores = rng.uniform(0.5, 1.0, size=n).astype(np.float32)
+    scores[::13] = np.float32(0.75)                                     # ties
+    idxs = rng.integers(0, images, size=n)
+    want = M._batched_nms(boxes, scores, idxs, thr, method, plus_one)
+    assert n >= m.NMS_DEVICE_MIN
+    got = m._bnms(boxes, scores, idxs, thr, method, plus_one)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert 0 < want.size < n
