@@ -469,6 +469,11 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
     const int tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * p.tiles_n;
     const int G = gridDim.x, KT = p.ktiles;
+    // Tiles b, b + G, ...: the 20-80 column tiles of one row tile run on all eight XCDs at once and every L2 fetches that A tile for
+    // itself (FETCH_SIZE x 2 = 2.86 GB per launch against 337 MB of operands, GEGLU K = 320 at B_eff 128).  Measured alternative: each XCD
+    // owning whole row tiles (its 64 workgroups walking [tm][tn] in order) cut that to 517 MB and was SLOWER — 575 vs 593 TFLOP/s at
+    // K = 320, 719 vs 795 at K = 640, 832 vs 922 at K = 1280, batch 64 15.30 vs 15.37 images/s: the re-reads are served by the
+    // Infinity Cache, and 64 workgroups pulling the same three A tiles through one L2 at the same moment queue on its channels.
     if ((int)blockIdx.x >= ntiles) return;
     const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
     const int total = my_tiles * KT;
