@@ -27,6 +27,18 @@ inline GnGeom gn_geometry(int c0, int c1, int batch, int hw, int groups) {
     g.C0 = c0; g.C1 = c1; g.C = c0 + c1; g.HW = hw; g.groups = groups; g.cpg = g.C / groups;
     int sw = g.cpg / gn_gcd(g.cpg, 8) * 8;                       // lcm(cpg, 8)
     while (sw / 8 < 8 && g.C % (sw * 2) == 0) sw *= 2;            // at least 8 vector columns when possible
+    {
+        // large tensors: slices of whole 128-byte lines (lcm(cpg, 64) channels) when that fits a workgroup — an 80-channel slice is a
+        // 160-byte piece of every pixel row, i.e. 2-3 partially used lines per piece, each line shared with the neighbouring slice's
+        // workgroup.  B_eff 128 (tools/bench_norm.py): 64x64x320 293 -> 225 us (3.4 -> 4.5 TB/s incl. the statistics re-read),
+        // 32x32x640 139 -> 122, 16x16x1280 66 -> 53; batch 64 15.08 -> 15.28 images/s.  At B_eff 2 the fewer, fatter workgroups lose
+        // (14.5 -> 20.6 us) and up to batch 8 it is a wash: only from IDB_GN_ALIGN elements on (default 16 Mi = 32 MB; 0: never).
+        static const long long env_align = [] { const char* e = getenv("IDB_GN_ALIGN"); return e ? atoll(e) : 16LL << 20; }();
+        const int sa = g.cpg / gn_gcd(g.cpg, 64) * 64;
+        if (env_align > 0 && (long long)batch * hw * g.C >= env_align && g.C0 % 64 == 0 && g.C1 % 64 == 0 && g.C % sa == 0 && sa / 8 <= GN_THREADS &&
+            sa / g.cpg <= 64)
+            sw = sa;
+    }
     g.SW = sw; g.cols = sw / 8; g.PR = GN_THREADS / g.cols; g.nslices = g.C / sw; g.gps = sw / g.cpg;
     // enough pixel chunks that the grid has >= ~1024 workgroups, each with >= 2 pixels per thread row
     int want = (1024 + batch * g.nslices - 1) / (batch * g.nslices);
