@@ -474,6 +474,8 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
     // owning whole row tiles (its 64 workgroups walking [tm][tn] in order) cut that to 517 MB and was SLOWER — 575 vs 593 TFLOP/s at
     // K = 320, 719 vs 795 at K = 640, 832 vs 922 at K = 1280, batch 64 15.30 vs 15.37 images/s: the re-reads are served by the
     // Infinity Cache, and 64 workgroups pulling the same three A tiles through one L2 at the same moment queue on its channels.
+    // Also measured: a 64x128 form with three workgroups per CU (more loads in flight against the one-round-trip K-step): 480 vs 574,
+    // 624 vs 756, 676 vs 896 TFLOP/s — half the rows per weight tile costs more than the third workgroup hides.
     if ((int)blockIdx.x >= ntiles) return;
     const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
     const int total = my_tiles * KT;
