@@ -272,6 +272,7 @@ extern "C" int idb_attention(const void* q, int32_t q_ld, const void* k, const v
     const bool small = blocks128 < 128;
     // about one 128-row workgroup per CU and a long key sweep: 8 waves, key halves split between wave pairs (attn_kernel)
     static const int env_ks = [] { const char* e = getenv("IDB_ATTN_KSPLIT"); return e ? atoi(e) : 1; }();
+    // (on larger grids the 8-wave form loses: batch 64 15.44 -> 15.22 images/s, batch 8 14.16 -> 13.96 with it everywhere)
     const bool ksplit = env_ks && !small && !causal && blocks128 < 512 && n_kv >= 512;
     // 257-511 workgroups of 128 rows = two uneven rounds (the CUs that get two set the time): 192-row workgroups (12 waves, three
     // per SIMD) when that grid fits one round — the 64x64 level at batch 1: 320 -> 220 workgroups
