@@ -457,8 +457,9 @@ class HipEngine:
             d.ln_stats, d.ln_tiles, d.ln_u, d.ln_v, d.ln_eps = ln[0].data_ptr(), ln[1], ln[2].data_ptr(), ln[3].data_ptr(), ln[4]
         gn_part = None
         if gn_stats and self._gn_fuse and (oh * ow) % 64 == 0 and oh * ow <= 4096 and not geglu and not out_f32 and n % gn_stats == 0:
-            # the GroupNorm that consumes `out` next gets its first pass from this GEMM's split-K reduce launch (idb_kernels.h);
-            # without a split there is no launch to ride on and the ordinary two-pass GroupNorm is at least as good
+            # the GroupNorm that consumes `out` next gets its first pass from this GEMM: from its split-K reduce launch, or — without a
+            # split — from its own LDS-staged epilogue when the column tiles hold whole groups (idb_kernels.h); otherwise the library
+            # would add a statistics launch and the ordinary two-pass GroupNorm is at least as good
             mode = self.lib.idb_gemm_emits_gn_partials(C.byref(d), gn_stats)     # 1: split-K reduce launch, 2: the GEMM's own epilogue
             if mode == 2 and not self._gn_epi:
                 mode = 0
