@@ -133,3 +133,28 @@ def test_unet_forward_with_and_without_the_fold(lib, dtype):
     ref0 = O.unet_forward(usd, ucfg, x, 501, ctx)
     got0 = pipe.unet(x.to(DEV), 501, ctx.to(DEV), return_dict=False)[0].cpu()
     assert ((got0 - ref0).norm() / ref0.norm()).item() < rel_tol
+
+
+def test_feed_forward_in_row_chunks_matches_the_single_piece(lib):
+    """engine._ff_chunk_bytes: ff.net.0 -> ff.net.2 over row chunks (default for intermediates beyond 320 MB) against the one-piece
+    form on the reduced graph with a chunk limit small enough to trigger; the GEMM plans differ with M, so equality is to rounding."""
+    from faceposegenerator_amd import spec as S, weights as W
+    from faceposegenerator_amd.pipeline import StableDiffusionPipeline
+    from oracle import sd21_oracle as O
+    ucfg, vcfg = S.TINY_UNET, S.TINY_VAE
+    usd = W.synth_unet(ucfg, 7)
+    pipe = StableDiffusionPipeline(ucfg, vcfg, usd, W.synth_vae(vcfg, 8), torch_dtype="f16").to(DEV)
+    eng = pipe._engine()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 4, 32, 32, generator=g)
+    ctx = torch.randn(4, 77, ucfg.cross_attention_dim, generator=g)
+    ref = O.unet_forward(usd, ucfg, x, 501, ctx)
+    eng._ff_chunk_bytes = 0
+    whole = pipe.unet(x.to(DEV), 501, ctx.to(DEV), return_dict=False)[0].cpu()
+    n_whole = eng.last_forward_launches
+    eng._ff_chunk_bytes = 64 << 10                     # 64 KB of intermediate per chunk: every transformer block splits
+    parts = pipe.unet(x.to(DEV), 501, ctx.to(DEV), return_dict=False)[0].cpu()
+    assert eng.last_forward_launches > n_whole
+    e_w, e_p = ((whole - ref).norm() / ref.norm()).item(), ((parts - ref).norm() / ref.norm()).item()
+    assert e_p < 3e-3 and abs(e_p - e_w) < 5e-4, (e_w, e_p)
+    assert ((parts - whole).norm() / whole.norm()).item() < 2e-3
