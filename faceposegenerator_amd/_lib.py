@@ -20,7 +20,7 @@ IDB_MAX_SRC = 4
 EXPORTS = [
     "idb_version", "idb_launch_count", "idb_last_error", "idb_device_check",
     "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm_row_stats_tiles", "idb_gemm_folds_layernorm", "idb_gemm_emits_gn_partials", "idb_gemm",
-    "idb_pack_conv_weight", "idb_pack_matrix", "idb_lora_merge", "idb_lora_merge_scaled",
+    "idb_pack_conv_weight", "idb_pack_matrix", "idb_tiled_weight_bytes", "idb_tile_weight", "idb_lora_merge", "idb_lora_merge_scaled", "idb_pack_matrix_scaled", "idb_ln_fold_vectors",
     "idb_groupnorm_workspace_bytes", "idb_groupnorm", "idb_layernorm", "idb_groupnorm_stats",
     "idb_hconv_workspace_bytes", "idb_hconv_plan", "idb_hconv",
     "idb_attention", "idb_embed_tokens", "idb_softmax_rows",
@@ -47,7 +47,7 @@ class GemmDesc(C.Structure):
                 ("split_k", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float), ("flags", C.c_int32), ("act", C.c_int32),
                 ("counters", C.c_void_p), ("counters_len", C.c_int32), ("gn_partials", C.c_void_p), ("gn_groups", C.c_int32),
                 ("row_stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_tiles", C.c_int32), ("ln_u", C.c_void_p),
-                ("ln_v", C.c_void_p), ("ln_eps", C.c_float), ("pad_mode", C.c_int32)]
+                ("ln_v", C.c_void_p), ("ln_eps", C.c_float), ("pad_mode", C.c_int32), ("w_layout", C.c_int32)]
 
 
 class HconvSeg(C.Structure):
@@ -103,6 +103,10 @@ def load() -> C.CDLL:
         "idb_lora_merge_scaled": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, i32, vp]),
         "idb_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
         "idb_pack_matrix": (C.c_int, [vp, vp, i64, i64, i32, i32, vp]),
+        "idb_pack_matrix_scaled": (C.c_int, [vp, vp, i64, i64, i32, vp, i32, vp]),
+        "idb_ln_fold_vectors": (C.c_int, [vp, vp, vp, i32, f32, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]),
+        "idb_tiled_weight_bytes": (sz, [i64, i64]),
+        "idb_tile_weight": (C.c_int, [vp, vp, i64, i64, i32, vp]),
         "idb_lora_merge": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, i32, vp]),
         "idb_groupnorm_workspace_bytes": (sz, [i32, i32, i32]),
         "idb_groupnorm": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp, sz, vp, i32, vp, i32, vp]),

@@ -105,9 +105,9 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + j * RS + lrow;
-        w_voff[j] = (n < p.N && j * RS + lrow < BN) ? (unsigned)n * p.w_row_bytes + cg16 : IDB_OOB;
+        w_voff[j] = (n < p.N && j * RS + lrow < BN) ? (unsigned)(n >> 4) * p.w_blk_bytes + (unsigned)(n & 15) * p.w_row_bytes + cg16 : IDB_OOB;
     }
-    unsigned w_soff = (unsigned)kt0 * 128u;
+    unsigned w_soff = (unsigned)kt0 * p.w_kstep;
 
     // ---- K-step state: source s, tap (0..8; a 1x1 source sits on the centre tap 4), channel offset c0.
     // Per-row voffsets (pixel address, zero padding -> out-of-range) are recomputed only when the tap or the
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * THREADS + wave * 64) * 16), 16, w_voff[j], w_soff, 0, 0);
-        w_soff += 128u;
+        w_soff += p.w_kstep;
         c0 += 64;
         if (c0 == cur_c) {
             c0 = 0;
@@ -282,9 +282,9 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_rs(const GemmParams p)
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const int n = n0 + j * 32 + lrow;
-        w_voff[j] = n < p.N ? (unsigned)n * p.w_row_bytes + c16 : IDB_OOB;
+        w_voff[j] = n < p.N ? (unsigned)(n >> 4) * p.w_blk_bytes + (unsigned)(n & 15) * p.w_row_bytes + c16 : IDB_OOB;
     }
-    unsigned w_soff = (unsigned)kt0 * 128u;
+    unsigned w_soff = (unsigned)kt0 * p.w_kstep;
 
     int s = 0, tap = 0, c0 = 0, cur_c = 64, tap_end = 9;
     {
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_rs(const GemmParams p)
         for (int i = 0; i < MF; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[i], a_soff, 0);
 #pragma unroll
         for (int j = 0; j < NF; ++j) wreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_voff[j], w_soff, 0);
-        w_soff += 128u;
+        w_soff += p.w_kstep;
         c0 += 64;
         if (c0 == cur_c) {
             c0 = 0;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             const int n = tn * BN + j * 32 + lrow;
-            w_voff[j] = n < p.N ? (unsigned)n * p.w_row_bytes + cg16 : IDB_OOB;
+            w_voff[j] = n < p.N ? (unsigned)(n >> 4) * p.w_blk_bytes + (unsigned)(n & 15) * p.w_row_bytes + cg16 : IDB_OOB;
         }
     };
     set_tile(lt);
@@ -510,9 +510,10 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_pl(const GemmParams p)
 #pragma unroll
         for (int i = 0; i < MF; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(sA + (i * 256 + wave * 64) * 16), 16, a_voff[i], soff, 0, 0);
+        const unsigned wsoff = (unsigned)lk * p.w_kstep;
 #pragma unroll
         for (int j = 0; j < NF; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * 256 + wave * 64) * 16), 16, w_voff[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * 256 + wave * 64) * 16), 16, w_voff[j], wsoff, 0, 0);
         if (++lk == KT) {
             lk = 0;
             lt += G;
@@ -701,7 +702,8 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     IDB_REQUIRE(d->act == 0 || (d->act == 1 && !d->geglu && !d->residual), "idb_gemm: act must be 0, or 1 (GELU) without GEGLU/residual");
     if (d->sample_bias) IDB_REQUIRE(d->sample_bias_ld == 0 || d->sample_bias_ld >= d->n, "idb_gemm: sample_bias_ld must be 0 (broadcast) or >= n");
 
-    IDB_REQUIRE((long long)d->n * K * 2 < (1LL << 31), "idb_gemm: weight matrix is >= 2 GiB");
+    IDB_REQUIRE(((long long)d->n + 15) / 16 * 16 * K * 2 < (1LL << 31), "idb_gemm: weight matrix is >= 2 GiB");
+    IDB_REQUIRE(d->w_layout == 0 || d->w_layout == 1, "idb_gemm: w_layout must be 0 (rows) or 1 (idb_tile_weight)");
     pl->M = (int)M;
     pl->K = K;
     pl->ktiles = (int)(K / 64);
@@ -1008,8 +1010,17 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.OW = d->out_w;
     p.stride = d->stride;
     p.pad = d->pad_mode == 1 ? 0 : 1;
-    p.w_row_bytes = (unsigned)(pl.K * 2);
-    p.w_bytes = (unsigned)((long long)d->n * pl.K * 2);
+    if (d->w_layout == 1) {          // K-tiled 16-row blocks (idb_tile_weight): [ceil(n/16)][K/64][16 rows][64 k]
+        p.w_row_bytes = 128u;
+        p.w_kstep = 2048u;
+        p.w_blk_bytes = (unsigned)pl.ktiles * 2048u;
+        p.w_bytes = (unsigned)(((long long)d->n + 15) / 16 * pl.ktiles * 2048);
+    } else {
+        p.w_row_bytes = (unsigned)(pl.K * 2);
+        p.w_kstep = 128u;
+        p.w_blk_bytes = (unsigned)(pl.K * 32);
+        p.w_bytes = (unsigned)((long long)d->n * pl.K * 2);
+    }
     p.ktiles = pl.ktiles;
     p.kt_per_split = pl.kt_per_split;
     {

@@ -13,7 +13,8 @@ struct GemmSrcK {
 struct GemmParams {
     GemmSrcK src[IDB_MAX_SRC];
     int M, N, HW, OW, stride, pad;
-    unsigned w_row_bytes, w_bytes;
+    unsigned w_row_bytes, w_bytes;   // w_row_bytes: bytes between consecutive weight rows inside a 16-row block
+    unsigned w_blk_bytes, w_kstep;   // bytes between 16-row blocks / between K-steps of one row (idb_gemm_desc.w_layout; idb_gemm kernels only)
     int ktiles, kt_per_split, splitk;
     int slab_swc;   // 0: split-K slabs are [z][M][N] row-major; else [z][M/64][N/swc][64][swc] blocks = the windows of idb_splitk_reduce_gn_kernel
     int xcd_mode;   // 0: tiles dealt to XCDs in runs, K-split on grid z; 1/2: one K-slice per XCD (group), see idb_gemm_kernel

@@ -298,6 +298,57 @@ __global__ __launch_bounds__(256) void pack_matrix_kernel(const float* __restric
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void pack_matrix_scaled_kernel(const float* __restrict__ src, T* __restrict__ dst, long long rows,
+                                                                 long long cols, int geglu, const float* __restrict__ cs) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long long r = i / cols, c = i - r * cols;
+    const long long sr = geglu ? geglu_src_row(r, rows) : r;
+    dst[i] = from_f32<T>(src[sr * cols + c] * cs[c]);
+}
+
+// one wave per output row: u = row sum of the rounded folded matrix, v = (W + scale B A) beta + bias in fp32
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const float* __restrict__ w, const float* __restrict__ a, const float* __restrict__ bm,
+                                                              int rank, float scale, const T* __restrict__ wq, const float* __restrict__ beta,
+                                                              const float* __restrict__ bias, float* __restrict__ u, float* __restrict__ v,
+                                                              long long rows, long long cols, int geglu) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const long long sr = geglu ? geglu_src_row(r, rows) : r;
+    float su = 0.f, sv = 0.f;
+    for (long long c = lane; c < cols; c += 64) {
+        su += to_f32<T>(wq[r * cols + c]);
+        sv += w[sr * cols + c] * beta[c];
+    }
+    for (int j = 0; j < rank; ++j) {
+        float ab = 0.f;
+        for (long long c = lane; c < cols; c += 64) ab += a[(long long)j * cols + c] * beta[c];
+        sv += scale * bm[sr * rank + j] * ab;       // summed over the lanes below together with the W term
+    }
+    su = wave_sum(su);
+    sv = wave_sum(sv);
+    if (lane == 0) {
+        u[r] = su;
+        v[r] = sv + (bias ? bias[r] : 0.f);
+    }
+}
+
+// [n][k] -> [ceil(n/16)][k/64][16][64]: one thread per 16-byte chunk of the destination (both element types are 2 bytes)
+__global__ __launch_bounds__(256) void tile_weight_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long n, long long k) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long kt = k >> 6, nb = (n + 15) >> 4;
+    if (i >= nb * kt * 128) return;
+    const int c8 = (int)(i & 7), r = (int)((i >> 3) & 15);
+    const long long t = i >> 7, ktile = t % kt, blk = t / kt;
+    const long long row = blk * 16 + r;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < n) v = src[(row * k + ktile * 64) / 8 + c8];
+    dst[i] = v;
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void lora_merge_kernel(const float* __restrict__ w, const float* __restrict__ a,
                                                          const float* __restrict__ bm, T* __restrict__ dst,
                                                          long long rows, long long cols, int rank, float scale) {
@@ -481,6 +532,44 @@ extern "C" int idb_pack_matrix(const float* src, void* dst, int64_t rows, int64_
     DISPATCH_T(dtype, hipLaunchKernelGGL((pack_matrix_kernel<__bf16>), dim3(nb), dim3(256), 0, st, src, (__bf16*)dst, (long long)rows, (long long)cols, geglu),
                hipLaunchKernelGGL((pack_matrix_kernel<_Float16>), dim3(nb), dim3(256), 0, st, src, (_Float16*)dst, (long long)rows, (long long)cols, geglu));
     IDB_CHECK_LAUNCH("idb_pack_matrix");
+    return IDB_OK;
+}
+
+extern "C" int idb_pack_matrix_scaled(const float* src, void* dst, int64_t rows, int64_t cols, int32_t geglu, const float* col_scale,
+                                      int32_t dtype, void* stream) {
+    IDB_REQUIRE(idb_is_operand_dtype(dtype) && src && dst && col_scale && rows > 0 && cols > 0, "idb_pack_matrix_scaled: bad args");
+    IDB_REQUIRE(!geglu || rows % 32 == 0, "idb_pack_matrix_scaled: GEGLU packing needs rows %% 32 == 0");
+    const unsigned nb = blocks_for(rows * cols);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pack_matrix_scaled_kernel<__bf16>), dim3(nb), dim3(256), 0, st, src, (__bf16*)dst, (long long)rows, (long long)cols, geglu, col_scale),
+               hipLaunchKernelGGL((pack_matrix_scaled_kernel<_Float16>), dim3(nb), dim3(256), 0, st, src, (_Float16*)dst, (long long)rows, (long long)cols, geglu, col_scale));
+    IDB_CHECK_LAUNCH("idb_pack_matrix_scaled");
+    return IDB_OK;
+}
+
+extern "C" int idb_ln_fold_vectors(const float* w, const float* lora_a, const float* lora_b, int32_t rank, float scale, const void* w_folded,
+                                   const float* beta, const float* bias, float* u, float* v, int64_t rows, int64_t cols, int32_t geglu,
+                                   int32_t dtype, void* stream) {
+    IDB_REQUIRE(idb_is_operand_dtype(dtype) && w && w_folded && beta && u && v && rows > 0 && cols > 0 && rank >= 0 && rank <= 16 &&
+                    (rank == 0 || !lora_a || lora_b), "idb_ln_fold_vectors: bad args");
+    IDB_REQUIRE(!geglu || rows % 32 == 0, "idb_ln_fold_vectors: GEGLU row order needs rows %% 32 == 0");
+    const int rk = lora_a ? rank : 0;
+    const unsigned nb = (unsigned)((rows + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fold_vectors_kernel<__bf16>), dim3(nb), dim3(256), 0, st, w, lora_a, lora_b, rk, scale, (const __bf16*)w_folded, beta, bias, u, v, (long long)rows, (long long)cols, geglu),
+               hipLaunchKernelGGL((ln_fold_vectors_kernel<_Float16>), dim3(nb), dim3(256), 0, st, w, lora_a, lora_b, rk, scale, (const _Float16*)w_folded, beta, bias, u, v, (long long)rows, (long long)cols, geglu));
+    IDB_CHECK_LAUNCH("idb_ln_fold_vectors");
+    return IDB_OK;
+}
+
+extern "C" size_t idb_tiled_weight_bytes(int64_t n, int64_t k) { return n > 0 && k > 0 ? (size_t)((n + 15) / 16 * 16 * k * 2) : 0; }
+
+extern "C" int idb_tile_weight(const void* src, void* dst, int64_t n, int64_t k, int32_t dtype, void* stream) {
+    IDB_REQUIRE(idb_is_operand_dtype(dtype) && src && dst && n > 0 && k > 0 && k % 64 == 0 && idb_aligned16(src) && idb_aligned16(dst),
+                "idb_tile_weight: needs operand dtype, 16-byte aligned pointers, k %% 64 == 0");
+    const unsigned nb = blocks_for((n + 15) / 16 * (k / 64) * 128);
+    hipLaunchKernelGGL(tile_weight_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, (long long)n, (long long)k);
+    IDB_CHECK_LAUNCH("idb_tile_weight");
     return IDB_OK;
 }
 

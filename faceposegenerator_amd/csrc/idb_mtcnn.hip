@@ -97,7 +97,7 @@ inline int pool_out(int n, int k, int s) {              // ceil_mode, padding 0 
 
 // Suppression bit matrix of greedy NMS (facenet_pytorch detect_face.py: torchvision batched_nms "Union", nms_numpy "Min"): boxes come
 // sorted by descending score; bit j of mask[i][j / 64] says "box i, if kept, removes box j" (j > i, same image, overlap not <= thr:
-// a NaN overlap of two degenerate boxes removes, as `order = rest[o <= thr]` does on the host).  fp32 arithmetic in exactly the host
+// a NaN overlap of two degenerate boxes removes under "Min" and keeps under "Union", as mtcnn._nms does on the host).  fp32 arithmetic in exactly the host
 // routine's operation order with contraction off (__f*_rn), so the host scan over these words keeps the same boxes as
 // mtcnn._nms.  One wave per 64 x 64 block, the column boxes through LDS.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ image, int n, float thr,
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
         const float h = fmaxf(0.f, __fadd_rn(__fsub_rn(fminf(y2, cb[k][3]), fmaxf(y1, cb[k][1])), one));
         const float inter = __fmul_rn(w, h);
         const float o = use_min ? __fdiv_rn(inter, fminf(area, cb[k][4])) : __fdiv_rn(inter, __fsub_rn(__fadd_rn(area, cb[k][4]), inter));
-        if (!(o <= thr)) bits |= 1ull << k;
+        if (use_min ? !(o <= thr) : (o > thr)) bits |= 1ull << k;      // NaN (0 / 0 of degenerate boxes): Min drops, Union keeps (mtcnn._nms)
     }
     mask[(long long)i * words + bw] = bits;
 }

@@ -174,14 +174,14 @@ def shard_work(items: Sequence[WorkItem], rank: int, world: int) -> List[WorkIte
     return [it for it in items if it.id_number % world == rank]
 
 
-def all_gather_images(local: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
+def all_gather_images(local: torch.Tensor, counts: Sequence[int], group=None, force: bool = False) -> torch.Tensor:
     """One all-gather of uint8 images.  `local` is [n_local, H, W, 3]; `counts[r]` is rank r's true count.
     Ranks pad to max(counts) (equal counts are required by the collective); the pad is dropped afterwards.
     Returns [sum(counts), H, W, 3] in rank order on every rank."""
     import torch.distributed as dist
     world = len(counts)
-    if world == 1 or not (dist.is_available() and dist.is_initialized()):
-        return local
+    if (world == 1 and not force) or not (dist.is_available() and dist.is_initialized()):
+        return local                                    # force: run the collective at world size 1 too (plumbing test)
     cap = max(counts)
     shape = (cap,) + tuple(local.shape[1:])
     buf = torch.zeros(shape, dtype=torch.uint8, device=local.device)

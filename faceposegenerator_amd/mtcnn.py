@@ -80,8 +80,9 @@ def synth_weights(seed: int = 5) -> Dict[str, SD]:
 
 # ---- host control logic (numpy; upstream: facenet_pytorch/models/utils/detect_face.py) -------------------------------------
 def _nms(boxes: np.ndarray, scores: np.ndarray, thr: float, method: str = "Union", plus_one: bool = False) -> np.ndarray:
-    """Greedy NMS in descending score order.  Union: IoU > thr suppresses (torchvision.ops.nms: areas without +1); Min: overlap over
-    the smaller box, areas with +1 (upstream's nms_numpy)."""
+    """Greedy NMS in descending score order.  Union: IoU > thr suppresses (torchvision.ops.nms: areas without +1; a NaN overlap of two
+    zero-area boxes is NOT > thr, so both stay, as torchvision keeps them); Min: overlap over the smaller box, areas with +1, kept iff
+    o <= thr (upstream's nms_numpy: a NaN overlap drops the box)."""
     if boxes.shape[0] == 0:
         return np.zeros((0,), dtype=np.int64)
     x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
@@ -96,8 +97,9 @@ def _nms(boxes: np.ndarray, scores: np.ndarray, thr: float, method: str = "Union
         w = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + one)
         h = np.maximum(0.0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + one)
         inter = w * h
-        o = inter / np.minimum(area[i], area[rest]) if method == "Min" else inter / (area[i] + area[rest] - inter)
-        order = rest[o <= thr]
+        with np.errstate(invalid="ignore", divide="ignore"):        # 0 / 0 between degenerate boxes: handled by the comparisons below
+            o = inter / np.minimum(area[i], area[rest]) if method == "Min" else inter / (area[i] + area[rest] - inter)
+        order = rest[o <= thr] if method == "Min" else rest[~(o > thr)]
     return np.asarray(keep, dtype=np.int64)
 
 
@@ -351,8 +353,7 @@ class MTCNN:
             if self.select_largest:
                 order = np.argsort((bb[:, 2] - bb[:, 0]) * (bb[:, 3] - bb[:, 1]), kind="stable")[::-1]
                 bb, pp, ll = bb[order], pp[order], ll[order]
-            if not self.keep_all:
-                bb, pp, ll = bb[:1], pp[:1], ll[:1]
+            # every face is returned, as upstream's detect() does: keep_all only acts in forward() / select_boxes there
             out_b.append(bb), out_p.append(pp), out_l.append(ll)
         ob, op, ol = np.empty(len(out_b), dtype=object), np.empty(len(out_b), dtype=object), np.empty(len(out_b), dtype=object)
         for i in range(len(out_b)):

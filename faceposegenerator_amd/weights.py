@@ -46,8 +46,121 @@ def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, rich: bool =
     return sd
 
 
-def synth_unet(cfg: S.UNetConfig = S.SD21_UNET, seed: int = 1234) -> SD:
-    return synth_state_dict(S.unet_param_shapes(cfg), seed)
+def synth_unet(cfg: S.UNetConfig = S.SD21_UNET, seed: int = 1234, calibrated: bool = False) -> SD:
+    sd = synth_state_dict(S.unet_param_shapes(cfg), seed)
+    return calibrate_unet(sd, cfg) if calibrated else sd
+
+
+CALIB_K = 2.0           # value of the constant companion channels of a pass-through lane pair
+CALIB_OUT_SCALE = 0.3   # scale of the random part of conv_out: eps = x_t + 0.3 * conv_out_random(...) (std ~0.14 at full size)
+
+
+def calibrate_unet(sd: SD, cfg: S.UNetConfig, out_scale: float = CALIB_OUT_SCALE) -> SD:
+    """Seeded N(0, 1/fan_in) weights make eps uncorrelated with x_t, and a 30-step DDPM chain then blows the latents up by
+    1/sqrt(alpha_bar_T) (std 1.4 -> 20): the regime a trained denoiser never visits (SURVEY.md §7 step 1 asks for activations that
+    stay O(1)).  A trained eps-model's output is x_t plus a context-dependent correction; this edit gives the synthetic network that
+    shape, by construction and without running it:
+
+      * a pass-through LANE PAIR per latent channel c: two channels of conv_in carry +x_c and -x_c (identity taps, no bias); the
+        same channels of the LAST up resnet (which receives conv_in's output as its skip) copy them from the skip (conv2 and
+        shortcut rows replaced), and the following transformer's proj_out adds nothing to them;
+      * the remaining channels of the pair's GroupNorm group(s) carry the constants +-K along the same path, so that conv_norm_out
+        sees groups whose mean and variance are fixed by construction (x_t has unit variance, +x and -x cancel in the mean):
+        h+ = (x - mu) / sd = -h-;
+      * conv_norm_out: gamma 1, beta 0 on the lanes, gamma = beta = 0 on the constants; SiLU then gives silu(h) and silu(-h), whose
+        DIFFERENCE is exactly h (sigmoid(h) + sigmoid(-h) = 1): no offset to ride on, so 16-bit storage keeps its relative precision;
+      * conv_out: random part scaled by ``out_scale`` (and its expectation removed from the bias: a constant term would be summed by
+        all 30 steps), plus +sd / -sd on the centre taps of the pair, so that eps_c = x_c + out_scale * (random network).
+
+    Every other weight — all 16 transformer blocks, the other 21 resnets, every LoRA-affected matrix — stays the seeded random tensor."""
+    import math
+    sd = dict(sd)
+    lc, c0, G = cfg.in_channels, cfg.block_out_channels[0], cfg.norm_num_groups
+    cpg = c0 // G
+    g = S.unet_graph(cfg)
+    last = g.up[-1]["resnets"][-1]
+    if last.skip_channels != c0 or last.cout != c0:
+        raise ValueError("calibrate_unet: the last up resnet must take conv_in's output as its skip")
+    xch = last.cin - last.skip_channels
+    K = CALIB_K
+    if cpg == 2 and 2 * lc <= G:            # groups {+x, +K} and {-x, -K}: h- = -h+ with mu = K / 2, sd^2 = 1/2 + K^2/4
+        plus = [4 * c for c in range(lc)]
+        minus = [4 * c + 2 for c in range(lc)]
+        consts = {**{4 * c + 1: K for c in range(lc)}, **{4 * c + 3: -K for c in range(lc)}}
+        mu, sdev = K / 2.0, math.sqrt(0.5 + K * K / 4.0)
+    elif cpg >= 4 and cpg % 2 == 0 and lc <= G:   # one group {+x, -x, (cpg-2)/2 x (+K), (cpg-2)/2 x (-K)}: mu = 0
+        plus = [c * cpg for c in range(lc)]
+        minus = [c * cpg + 1 for c in range(lc)]
+        consts = {c * cpg + j: (K if j % 2 == 0 else -K) for c in range(lc) for j in range(2, cpg)}
+        mu, sdev = 0.0, math.sqrt((2.0 + (cpg - 2) * K * K) / cpg)
+    else:
+        raise ValueError("calibrate_unet needs 2 or an even number >= 4 of channels per GroupNorm group at the first level")
+    designed = plus + minus + sorted(consts)
+
+    def edit(name, fn):
+        t = sd[name].clone()
+        fn(t)
+        sd[name] = t
+
+    def conv_in_w(w):
+        w[designed] = 0.0
+        for c in range(lc):
+            w[plus[c], c, 1, 1] = 1.0
+            w[minus[c], c, 1, 1] = -1.0
+
+    def conv_in_b(b):
+        b[designed] = 0.0
+        for ch, k in consts.items():
+            b[ch] = k
+
+    edit("conv_in.weight", conv_in_w)
+    edit("conv_in.bias", conv_in_b)
+    edit(last.name + ".conv2.weight", lambda w: w.__setitem__(designed, 0.0))
+    edit(last.name + ".conv2.bias", lambda b: b.__setitem__(designed, 0.0))
+
+    def shortcut_w(w):
+        w[designed] = 0.0
+        for ch in designed:
+            w[ch, xch + ch, 0, 0] = 1.0
+
+    edit(last.name + ".conv_shortcut.weight", shortcut_w)
+    edit(last.name + ".conv_shortcut.bias", lambda b: b.__setitem__(designed, 0.0))
+    if g.up[-1]["attns"]:
+        a = g.up[-1]["attns"][-1].name
+        edit(a + ".proj_out.weight", lambda w: w.__setitem__(designed, 0.0))
+        edit(a + ".proj_out.bias", lambda b: b.__setitem__(designed, 0.0))
+
+    def norm_w(w):
+        w[plus + minus] = 1.0
+        w[sorted(consts)] = 0.0
+
+    edit("conv_norm_out.weight", norm_w)
+    edit("conv_norm_out.bias", lambda b: b.__setitem__(designed, 0.0))
+
+    # expectation of the random part: E[silu(gamma z + beta)] per channel for z ~ N(0,1) (what conv_norm_out emits) times the summed taps
+    z = torch.linspace(-6.0, 6.0, 2401, dtype=torch.float64)
+    pdf = torch.exp(-0.5 * z * z)
+    pdf = pdf / pdf.sum()
+    gam, bet = sd["conv_norm_out.weight"].double(), sd["conv_norm_out.bias"].double()
+    mean_act = (torch.nn.functional.silu(gam[:, None] * z[None, :] + bet[:, None]) * pdf[None, :]).sum(dim=1)      # [C]
+    w_rand = sd["conv_out.weight"].double() * out_scale
+    w_rand[:, designed] = 0.0                          # the random part does not read the designed channels
+    dc = (w_rand.sum(dim=(2, 3)) * mean_act[None, :]).sum(dim=1).float()                                          # [out_channels]
+
+    def conv_out_w(w):
+        w *= out_scale
+        w[:, designed] = 0.0
+        for c in range(lc):
+            w[c, plus[c], 1, 1] = sdev             # eps_c = sd * (silu(h+) - silu(h-)) = sd * h+ = x_c - mu
+            w[c, minus[c], 1, 1] = -sdev
+
+    def conv_out_b(b):
+        b *= out_scale
+        b += mu - dc
+
+    edit("conv_out.weight", conv_out_w)
+    edit("conv_out.bias", conv_out_b)
+    return sd
 
 
 def synth_vae(cfg: S.VAEConfig = S.SD21_VAE, seed: int = 4321) -> SD:

@@ -116,6 +116,10 @@ typedef struct {
     int32_t pad_mode;         /* taps=9 sources — 0: zero padding 1 on every side (nn.Conv2d padding=1); 1: padding on the
                                  bottom/right only, i.e. F.pad(x, (0,1,0,1)) + padding=0, the stride-2 Downsample2D of the VAE
                                  encoder (diffusers downsampling.py; AutoencoderKL.encode at train_ID-Booth.py:1001) */
+    int32_t w_layout;         /* 0: `w` is [n][K] rows (K contiguous); 1: K-tiled 16-row blocks written by idb_tile_weight,
+                                 [ceil(n/16)][K/64][16 rows][64 k]: the rows of one K-step of a column tile are whole 2 KiB runs and
+                                 a workgroup's K loop reads each of its row blocks as ONE contiguous stream (HBM pages, TLB reach)
+                                 instead of 128-byte pieces at a K*2-byte stride */
 } idb_gemm_desc;
 
 size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);
@@ -140,6 +144,10 @@ int idb_pack_conv_weight(const float* src, void* dst, int32_t cout, int32_t cin,
 /* [rows][cols] fp32 -> operand dtype, optional GEGLU row interleave (value/gate in 16-row groups). */
 int idb_pack_matrix(const float* src, void* dst, int64_t rows, int64_t cols, int32_t geglu,
                     int32_t dtype, void* stream);
+/* [n][k] operand dtype (k % 64 == 0) -> the K-tiled layout idb_gemm_desc.w_layout = 1 reads: [ceil(n/16)][k/64][16][64], rows
+ * past n zero-filled; dst holds idb_tiled_weight_bytes(n, k) bytes and must not overlap src. */
+size_t idb_tiled_weight_bytes(int64_t n, int64_t k);
+int idb_tile_weight(const void* src, void* dst, int64_t n, int64_t k, int32_t dtype, void* stream);
 /* dst[rows][cols] = W + scale * B[rows][r] * A[r][cols], fp32 in, operand dtype out: merged LoRA
  * (peft lora.Linear with merged weights; inference_ID-Booth.py:107). */
 int idb_lora_merge(const float* w, const float* lora_a, const float* lora_b, void* dst, int64_t rows,
@@ -148,6 +156,17 @@ int idb_lora_merge(const float* w, const float* lora_a, const float* lora_b, voi
  * lora_a == NULL (rank 0): dst = round(W * col_scale). */
 int idb_lora_merge_scaled(const float* w, const float* lora_a, const float* lora_b, void* dst, int64_t rows, int64_t cols,
                           int32_t rank, float scale, const float* col_scale, int32_t dtype, void* stream);
+/* idb_pack_matrix with every column k multiplied by col_scale[k] before the one rounding (GEGLU projection behind a folded LayerNorm). */
+int idb_pack_matrix_scaled(const float* src, void* dst, int64_t rows, int64_t cols, int32_t geglu, const float* col_scale,
+                           int32_t dtype, void* stream);
+/* The two column vectors of a LayerNorm folded into a projection (idb_gemm_desc.ln_u / ln_v), for output rows r = 0..rows-1
+ * (r -> source row sr through the GEGLU interleave when geglu = 1):
+ *   u[r] = sum_k float(w_folded[r][k])              w_folded: the ROUNDED gamma-scaled operand-dtype matrix the GEMM multiplies
+ *   v[r] = sum_k (W[sr][k] + scale * (B A)[sr][k]) * beta[k] + (bias ? bias[r] : 0)      fp32, W / A / B as idb_lora_merge
+ * lora_a == NULL or rank == 0: no adapter.  rank <= 16. */
+int idb_ln_fold_vectors(const float* w, const float* lora_a, const float* lora_b, int32_t rank, float scale, const void* w_folded,
+                        const float* beta, const float* bias, float* u, float* v, int64_t rows, int64_t cols, int32_t geglu,
+                        int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1 (norm part) / K6 — GroupNorm and LayerNorm.

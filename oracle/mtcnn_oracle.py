@@ -70,7 +70,7 @@ def nms(boxes, scores, thr, method="Union", plus_one=False):
     for i in range(n):
         if alive[i]:
             keep.append(i)
-            alive &= ~(ov[i] > thr)
+            alive &= (ov[i] <= thr) if method == "Min" else ~(ov[i] > thr)    # NaN: nms_numpy ("Min") drops, torchvision ("Union") keeps
             alive[i] = False
     return order[torch.tensor(keep, dtype=torch.long)]
 

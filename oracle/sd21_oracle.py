@@ -51,9 +51,14 @@ def _r(kind: str, t: Tensor) -> Tensor:
 
 
 # Second hook, for the fp8 path (BASELINE configs[4]): applied INSTEAD of ROUND to the GroupNorm+SiLU output that feeds a 3x3 conv of a
-# UNet ResnetBlock2D (the HIP engine writes that tensor as e4m3 straight from fp32).  ``fp8_quantize`` / ``fp8_weights`` are the
-# emulation of the engine's quantisers: one fixed scale for the activations, absmax / 448 per output channel for the weights.
+# UNet ResnetBlock2D (the HIP engine writes that tensor as e4m3 straight from fp32), called as ROUND_CONV_IN(tensor, scale) with the
+# layer's activation scale.  ``fp8_quantize`` / ``fp8_act_scale`` / ``fp8_weights`` are the emulation of the engine's quantisers:
+# (8 max|gamma| + max|beta|) / 448 per GroupNorm layer for the activations, absmax / 448 per output channel for the weights.
 ROUND_CONV_IN = None
+
+
+def fp8_act_scale(sd: SD, norm: str) -> float:
+    return float(8.0 * sd[norm + ".weight"].abs().max() + sd[norm + ".bias"].abs().max()) / 448.0
 
 
 def fp8_quantize(t: Tensor, scale: float) -> Tensor:
@@ -124,14 +129,14 @@ def merge_lora(sd: SD, lora: SD, scale: float = 1.0) -> SD:
 def resnet_block(sd: SD, p: str, x: Tensor, temb: Optional[Tensor], groups: int, eps: float) -> Tensor:
     fp8_in = ROUND_CONV_IN is not None and temb is not None          # UNet resnets only (the VAE's have no temb)
     h = F.group_norm(x, groups, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
-    h = ROUND_CONV_IN(F.silu(h)) if fp8_in else _r("act", F.silu(h))
+    h = ROUND_CONV_IN(F.silu(h), fp8_act_scale(sd, p + ".norm1")) if fp8_in else _r("act", F.silu(h))
     h = F.conv2d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
     if temb is not None:
         t = F.linear(F.silu(temb), sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"])
         h = h + t[:, :, None, None]
     h = _r("act", h)
     h = F.group_norm(h, groups, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps)
-    h = ROUND_CONV_IN(F.silu(h)) if fp8_in else _r("act", F.silu(h))
+    h = ROUND_CONV_IN(F.silu(h), fp8_act_scale(sd, p + ".norm2")) if fp8_in else _r("act", F.silu(h))
     h = F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
     if (p + ".conv_shortcut.weight") in sd:
         x = F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])

@@ -12,7 +12,10 @@ full : BASELINE configs[0] = SD-2.1-base shapes, 1 prompt, 64x64 latent, 4 DDPM 
 config1 : BASELINE configs[1] = the headline workload: SD-2.1-base shapes + rank-4 LoRA ("ID_1", synth_lora seed 1),
        batch 1, 64x64 latent, 30 DDPM steps, CFG 5.0 -> sd21_config1.npz (~10 minutes on 8 cores): latents after each of
        the 30 steps, final latents, decoded uint8 image, and eps (uncond, cond) of the steps in EPS_STEPS for the
-       teacher-forced per-step comparison
+       teacher-forced per-step comparison.  CALIBRATED synthetic weights (weights.calibrate_unet: eps = x_t + a network-dependent
+       correction, latents stay O(1) over the 30 steps like a trained model's; meta[8] = 1)
+batch3 : three distinct work items (prompt embeddings and initial latents) of the calibrated configs[1] network, ONE CFG forward at
+       t = timesteps[0]: eps (uncond, cond) -> sd21_batch3_eps.npz — the oracle side of the batch-64 teacher-forced test
 """
 import os
 import sys
@@ -32,8 +35,8 @@ def weight_fingerprint(sd, names):
     return np.array([float(sd[n].double().sum()) for n in names], dtype=np.float64)
 
 
-def run(ucfg, vcfg, useed, vseed, lora_seed, batch, side, steps, gs, fp_names):
-    usd, vsd = W.synth_unet(ucfg, useed), W.synth_vae(vcfg, vseed)
+def run(ucfg, vcfg, useed, vseed, lora_seed, batch, side, steps, gs, fp_names, calibrated=False):
+    usd, vsd = W.synth_unet(ucfg, useed, calibrated=calibrated), W.synth_vae(vcfg, vseed)
     lora_raw = W.synth_lora(ucfg, lora_seed) if lora_seed is not None else None
     g = torch.Generator().manual_seed(2024)
     pe = torch.randn(batch, 77, ucfg.cross_attention_dim, generator=g)
@@ -50,7 +53,7 @@ def run(ucfg, vcfg, useed, vseed, lora_seed, batch, side, steps, gs, fp_names):
         "eps_uncond": torch.stack([t[0] for t in trace]).numpy(), "eps_cond": torch.stack([t[1] for t in trace]).numpy(),
         "latents_per_step": torch.stack([t[2] for t in trace]).numpy(), "final_latents": lat.numpy(),
         "image_u8": O.to_uint8(img.clone()).numpy(), "noise_first4": noise.flatten()[:4].numpy(),
-        "meta": np.array([useed, vseed, -1 if lora_seed is None else lora_seed, batch, side, steps, 2024, 0]),
+        "meta": np.array([useed, vseed, -1 if lora_seed is None else lora_seed, batch, side, steps, 2024, 0, int(calibrated)]),
     }
 
 
@@ -72,13 +75,30 @@ def main():
         print("full: final latents std", d["final_latents"].std(), "image mean", d["image_u8"].mean())
     if "config1" in what:
         torch.set_num_threads(os.cpu_count() or 8)
-        d = run(S.SD21_UNET, S.SD21_VAE, 1234, 1235, 1, 1, 64, 30, 5.0, fp)
+        d = run(S.SD21_UNET, S.SD21_VAE, 1234, 1235, 1, 1, 64, 30, 5.0, fp + ["conv_out.weight", "conv_in.weight"], calibrated=True)
         d["eps_steps"] = np.array(EPS_STEPS)
         d["eps_uncond"] = d["eps_uncond"][EPS_STEPS].astype(np.float32)
         d["eps_cond"] = d["eps_cond"][EPS_STEPS].astype(np.float32)
         np.savez_compressed(os.path.join(HERE, "sd21_config1.npz"), **d)
         print("config1: final latents std", d["final_latents"].std(), "max", np.abs(d["final_latents"]).max(),
-              "image mean", d["image_u8"].mean())
+              "image mean", d["image_u8"].mean(), "per-step std", d["latents_per_step"].std(axis=(1, 2, 3, 4)).round(3),
+              "per-step max", np.abs(d["latents_per_step"]).max(axis=(1, 2, 3, 4)).round(2))
+    if "batch3" in what:
+        torch.set_num_threads(os.cpu_count() or 8)
+        ucfg = S.SD21_UNET
+        usd = W.synth_unet(ucfg, 1234, calibrated=True)
+        lora = O.normalize_lora_keys(W.synth_lora(ucfg, 1))
+        g = torch.Generator().manual_seed(4048)
+        pe = torch.randn(3, 77, ucfg.cross_attention_dim, generator=g)
+        ne = torch.randn(3, 77, ucfg.cross_attention_dim, generator=g)
+        x = torch.randn(3, 4, 64, 64, generator=g)
+        t = O.ddpm_timesteps(30)[0]
+        with torch.no_grad():
+            eps = O.unet_forward(usd, ucfg, torch.cat([x, x]), t, torch.cat([ne, pe]), lora)
+        np.savez_compressed(os.path.join(HERE, "sd21_batch3_eps.npz"), eps_uncond=eps[:3].numpy(), eps_cond=eps[3:].numpy(),
+                            meta=np.array([1234, 1, 4048, t, 3]), x_first4=x.flatten()[:4].numpy(),
+                            unet_fingerprint=weight_fingerprint(usd, fp + ["conv_out.weight"]))
+        print("batch3: eps std", eps.std().item(), "|eps - x| std", (eps - torch.cat([x, x])).std().item())
 
 
 if __name__ == "__main__":

@@ -36,3 +36,26 @@ def test_single_rank_fake_line_and_mismatched_world_size():
     assert r["n_gpus"] == 1 and r["config"]["parallelism"] == "single GPU"
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "64", "--ddpm-steps", "2"], {"WORLD_SIZE": "1", "RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def _torchrun(nproc, args, extra_env):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"OMP_NUM_THREADS": "1"})
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_forced_collectives_at_world_size_1_on_gloo():
+    """IDB_FORCE_DIST=1: the driver's launch form with ONE rank still initialises the process group and runs the all-gather, the
+    barriers and the MAX all-reduce (the -m gpu twin, tests/test_rccl_gpu.py, does the same on RCCL with the real pipeline)."""
+    p = _torchrun(1, ["--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "64", "--ddpm-steps", "2", "--batch", "2"],
+                  {"IDB_BENCH_FAKE": "1", "IDB_FORCE_DIST": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["config"]["forced_collectives"] == "gloo"

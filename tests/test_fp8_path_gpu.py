@@ -22,9 +22,8 @@ def _emulated(O, usd, ucfg, x, t, ctx, lora=None):
     for k, v in O.fp8_weights(usd).items():                       # the e4m3 weights are NOT re-rounded to f16 (exact in f16 anyway)
         if ".resnets." in k and k.endswith((".conv1.weight", ".conv2.weight")):
             wsd[k] = v
-    from faceposegenerator_amd.engine import HipEngine
     O.ROUND = lambda kind, z: z.half().float()
-    O.ROUND_CONV_IN = lambda z: O.fp8_quantize(z, HipEngine.X8_SCALE)
+    O.ROUND_CONV_IN = O.fp8_quantize                                  # (tensor, the layer's scale): oracle.fp8_act_scale = engine.fp8_act_scale
     try:
         with torch.no_grad():
             return O.unet_forward(wsd, ucfg, x, t, ctx, lora)

@@ -514,3 +514,71 @@ def test_gemm_epilogue_emits_groupnorm_partials_only_for_whole_groups(eng):
     assert mode(256, 2, 1280, 9, 1280) == 1           # batch-1 conv at 16x16: split-K, statistics from the reduce launch
     assert mode(4096, 128, 320, 9, 320, tile=9) == 0  # 128x128 tiles cut the groups
     assert mode(4096, 128, 320, 9, 336) == 0          # 336 / 32 is not an integer group width
+
+
+# ---------------------------------------------------------------------------------------------------
+# K-tiled weight layout (idb_tile_weight, idb_gemm_desc.w_layout = 1) and the folded-LayerNorm vectors
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k,tile,split_k", [
+    (256, 320, 320, 1, 1), (128, 160, 1280, 3, 4), (77, 256, 1024, 4, 3), (1000, 4, 576, 5, 1), (64, 3, 128, 5, 2),
+    (512, 640, 2560, 0, 0), (4096, 960, 320, 0, 0), (130, 1280, 1280, 0, 0), (128, 1280, 11520, 0, 0), (700, 640, 128, 11, 1),
+    (513, 250, 704, 19, 2), (300, 480, 1280, 18, 2), (200, 384, 640, 7, 3), (700, 320, 640, 16, 1), (256, 320, 320, 31, 1),
+    (5000, 320, 192, 41, 1), (66000, 960, 320, 41, 1), (300, 136, 64, 42, 1)])
+def test_gemm_tiled_weight_layout(eng, m, n, k, tile, split_k):
+    """The same GEMM from [n][K] rows and from the 16-row K-tiled blocks: bit-identical (only the addresses differ)."""
+    a = _rand((m, k), 21).to(eng.tdt)
+    w = _rand((n, k), 22, k ** -0.5).to(eng.tdt)
+    bias = _rand((n,), 23)
+    wt = eng.tile_weight(w)
+    assert wt.numel() == (n + 15) // 16 * 16 * k
+    blocks = wt.view((n + 15) // 16, k // 64, 16, 64)
+    wpad = torch.zeros(((n + 15) // 16 * 16, k), dtype=eng.tdt, device=DEV)
+    wpad[:n] = w
+    assert torch.equal(blocks.permute(0, 2, 1, 3).reshape(-1, k), wpad)          # the layout itself, incl. zero rows past n
+    ref = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, m, 1, 1, bias=bias, tile=tile, split_k=split_k, out_f32=(tile // 10 != 4))
+    out = eng.gemm([(a, k, 1, 1, 1, 0)], wt, n, m, 1, 1, bias=bias, tile=tile, split_k=split_k, out_f32=(tile // 10 != 4))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
+def test_conv_tiled_weight_layout(eng):
+    b, h, cin, cout = 2, 16, 128, 320
+    x = _rand((b, h, h, cin), 31).to(eng.tdt)
+    wc = _rand((cout, cin, 3, 3), 32, (9 * cin) ** -0.5)
+    w = eng._pack_conv(wc)
+    for tile in (0, 8, 6, 13):
+        ref = eng.gemm([(x, cin, 9, h, h, 0)], w, cout, b, h, h, tile=tile)
+        out = eng.gemm([(x, cin, 9, h, h, 0)], eng.tile_weight(w), cout, b, h, h, tile=tile)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("rows,cols,rank,geglu", [(320, 320, 4, 0), (960, 320, 0, 0), (2560, 320, 0, 1), (1280, 1280, 8, 0)])
+def test_ln_fold_vectors(eng, rows, cols, rank, geglu):
+    w = _rand((rows, cols), 41, cols ** -0.5)
+    gamma, beta, bias = 1.0 + 0.2 * _rand((cols,), 42), _rand((cols,), 43), _rand((rows,), 44)
+    la = _rand((rank, cols), 45, 0.25) if rank else None
+    lb = _rand((rows, rank), 46, 0.02) if rank else None
+    sc = 0.75
+    perm = eng._geglu_perm(rows).to(DEV) if geglu else torch.arange(rows, device=DEV)
+    merged = w.double() + (sc * (lb.double() @ la.double()) if rank else 0.0)
+    wq = torch.empty((rows, cols), dtype=eng.tdt, device=DEV)
+    if geglu:
+        from faceposegenerator_amd import _lib as L
+        L.check(eng.lib.idb_pack_matrix_scaled(w.data_ptr(), wq.data_ptr(), rows, cols, 1, gamma.data_ptr(), eng.dt, 0), "pack_scaled")
+        # one rounding of the exact product (v_fma_mix) vs torch's fp32 product rounded again: equal up to one output ulp
+        ref_q = (w.double() * gamma.double()[None, :])[perm]
+        assert ((wq.double() - ref_q).abs() <= (2.0 ** -8 if eng.dtype_name == "bf16" else 2.0 ** -11) * ref_q.abs() + 6e-8).all()      # + the f16 sub-normal step 2^-24
+    else:
+        wq.copy_((merged * gamma.double()[None, :]).float().to(eng.tdt))
+    u = torch.empty((rows,), dtype=torch.float32, device=DEV)
+    v = torch.empty((rows,), dtype=torch.float32, device=DEV)
+    from faceposegenerator_amd import _lib as L
+    L.check(eng.lib.idb_ln_fold_vectors(w.data_ptr(), None if la is None else la.data_ptr(), None if lb is None else lb.data_ptr(), rank, sc,
+                                        wq.data_ptr(), beta.data_ptr(), bias.data_ptr(), u.data_ptr(), v.data_ptr(), rows, cols, geglu, eng.dt, 0),
+            "idb_ln_fold_vectors")
+    torch.cuda.synchronize()
+    u_ref = wq.double().sum(dim=1)
+    v_ref = (merged @ beta.double())[perm] + bias.double()
+    assert (u.double() - u_ref).abs().max().item() < 2e-5 * max(1.0, u_ref.abs().max().item())
+    assert (v.double() - v_ref).abs().max().item() < 2e-5 * max(1.0, v_ref.abs().max().item())

@@ -412,8 +412,14 @@ def test_config1_golden_fixture_is_wellformed():
     """BASELINE configs[1] trajectory (30 steps, LoRA): structure + the first step reproduced by the oracle on the reduced checks
     the CPU suite can afford (scheduler tables and RNG stream; the full trajectory is regenerated by make_golden.py config1)."""
     gold = np.load(os.path.join(GOLD, "sd21_config1.npz"))
-    assert gold["meta"].tolist() == [1234, 1235, 1, 1, 64, 30, 2024, 0]
+    assert gold["meta"].tolist() == [1234, 1235, 1, 1, 64, 30, 2024, 0, 1]          # last entry: calibrated synthetic weights
     assert gold["latents_per_step"].shape == (30, 1, 4, 64, 64) and gold["final_latents"].shape == (1, 4, 64, 64)
+    # SURVEY.md §7 step 1: activations stay O(1) through the 30 steps (rounds 1-2: std 1.4 -> 20, max 77 on uncalibrated weights)
+    stds = gold["latents_per_step"].std(axis=(1, 2, 3, 4))
+    assert 0.25 < stds.min() and stds.max() < 1.3 and np.abs(gold["latents_per_step"]).max() < 6.0, (stds, np.abs(gold["latents_per_step"]).max())
+    assert np.abs(gold["latents_per_step"].mean(axis=(1, 2, 3, 4))).max() < 0.2
+    for e in (gold["eps_uncond"], gold["eps_cond"]):                                # eps has about unit variance at every stored step
+        assert 0.3 < e.std(axis=(1, 2, 3, 4)).min() and e.std(axis=(1, 2, 3, 4)).max() < 1.3
     assert np.array_equal(gold["latents_per_step"][-1], gold["final_latents"])
     assert gold["timesteps"].tolist() == O.ddpm_timesteps(30) == [1 + 33 * k for k in range(29, -1, -1)]
     assert gold["eps_steps"].tolist() == [0, 4, 9, 14, 19, 24, 29] and gold["eps_cond"].shape == (7, 1, 4, 64, 64)
@@ -424,3 +430,30 @@ def test_config1_golden_fixture_is_wellformed():
     e_u, e_c = torch.from_numpy(gold["eps_uncond"][0]), torch.from_numpy(gold["eps_cond"][0])
     prev, _ = O.ddpm_step(O.ddpm_tables(), O.ddpm_timesteps(30), 958, e_u + 5.0 * (e_c - e_u), noise[0], noise[1])
     assert np.abs(prev.numpy() - gold["latents_per_step"][0]).max() < 1e-5
+
+
+def test_calibrated_weights_keep_latents_of_order_one(tiny):
+    """weights.calibrate_unet: a 30-step CFG-5 DDPM chain on the reduced graph stays O(1) with the calibrated
+    weights and blows up with the plain N(0, 1/fan_in) ones; the edit touches only the lane rows of five modules."""
+    usd, _, lora_raw = tiny
+    cal = W.calibrate_unet(usd, S.TINY_UNET)
+    changed = sorted(k for k in usd if not torch.equal(usd[k], cal[k]))
+    last = S.unet_graph(S.TINY_UNET).up[-1]
+    assert changed == sorted(["conv_in.weight", "conv_in.bias", "conv_out.weight", "conv_out.bias", "conv_norm_out.weight", "conv_norm_out.bias",
+                              last["resnets"][-1].name + ".conv2.weight", last["resnets"][-1].name + ".conv2.bias",
+                              last["resnets"][-1].name + ".conv_shortcut.weight", last["resnets"][-1].name + ".conv_shortcut.bias",
+                              last["attns"][-1].name + ".proj_out.weight", last["attns"][-1].name + ".proj_out.bias"])
+    assert sum(v.numel() for v in cal.values()) == sum(v.numel() for v in usd.values())
+    g = torch.Generator().manual_seed(2024)
+    pe, ne = torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
+    noise = O.draw_noise(torch.Generator().manual_seed(0), 1, 30, (16, 16))
+    lora = O.normalize_lora_keys(lora_raw)
+    with torch.no_grad():
+        x = noise[0]
+        eps = O.unet_forward(cal, S.TINY_UNET, x, 958, pe, lora)
+        slope = ((eps * x).sum() / (x * x).sum()).item()
+        assert 0.9 < slope < 1.1 and (eps - slope * x).std().item() < 0.4           # eps = x_t + a smaller network-dependent part
+        lat_cal = O.sample(cal, S.TINY_UNET, pe, ne, noise, 30, 5.0, lora=lora)
+        lat_raw = O.sample(usd, S.TINY_UNET, pe, ne, noise, 30, 5.0, lora=lora)
+    assert lat_cal.std().item() < 2.0 and lat_cal.abs().max().item() < 8.0 and abs(lat_cal.mean().item()) < 0.6
+    assert lat_raw.std().item() > 8.0                                                # what rounds 1-2 measured parity on

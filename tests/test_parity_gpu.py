@@ -9,12 +9,11 @@ What is compared (measured values are printed, recorded in DESIGN.md section 2, 
     fp32 oracle run here on the host CPU, next to the SAME comparison for the oracle with the engine's rounding points
     emulated (oracle.ROUND): the engine must sit in the error class of its operand dtype, block by block.
 
-north_star states "latents within 1e-2 max-abs of the CPU fp32 reference".  On this synthetic-weight network the latents grow
-to std 20 over the 30 steps (a trained model keeps them at std ~1), and in absolute terms 16-bit storage cannot reach that
-bound: the emulated-rounding oracle — i.e. ANY implementation that stores f16 weights and activations, the reference's own
-`torch_dtype=torch.float16` run included — ends at 0.165 max-abs, the HIP engine at 0.174 (f16).  Normalised by the latent
-scale the f16 figure is 8.7e-3 (< 1e-2); bf16 is 7.2e-2.  The bounds below are 1.5x the measured values; the absolute 1e-2
-figure is printed as NOT met.
+north_star states "latents within 1e-2 max-abs of the CPU fp32 reference".  Round 3: the fixture is made with CALIBRATED synthetic
+weights (weights.calibrate_unet: eps = x_t + a network-dependent correction, as a trained eps-model's output is), so the latents
+stay O(1) over the 30 steps (std 1.0 -> 0.4, max < 5; tests/test_oracle_cpu.py asserts it) and the ABSOLUTE figures below can be
+read against the 1e-2 bound.  Rounds 1-2 used plain N(0, 1/fan_in) weights, whose chain blows the latents up to std 20; their
+figures (f16 0.157, bf16 1.21 max-abs) are in DESIGN.md's round history.  The bounds below are 1.5x the values measured on MI355X.
 """
 import math
 import os
@@ -48,9 +47,10 @@ def cfg1(lib):
     from faceposegenerator_amd import spec as S, weights as W
     path = os.path.join(GOLD, "sd21_config1.npz")
     gold = np.load(path)
-    useed, vseed, lseed, batch, side, steps, eseed, nseed = gold["meta"].tolist()
-    usd, vsd = W.synth_unet(S.SD21_UNET, useed), W.synth_vae(S.SD21_VAE, vseed)
-    assert np.allclose([float(usd[n].double().sum()) for n in FP_NAMES], gold["unet_fingerprint"], rtol=0, atol=1e-7), \
+    useed, vseed, lseed, batch, side, steps, eseed, nseed, calibrated = gold["meta"].tolist()
+    assert calibrated == 1, "sd21_config1.npz must be the calibrated-weights fixture (tests/golden/make_golden.py config1)"
+    usd, vsd = W.synth_unet(S.SD21_UNET, useed, calibrated=True), W.synth_vae(S.SD21_VAE, vseed)
+    assert np.allclose([float(usd[n].double().sum()) for n in FP_NAMES + ["conv_out.weight", "conv_in.weight"]], gold["unet_fingerprint"], rtol=0, atol=1e-7), \
         "synthetic weights differ from the ones the golden vectors were made with"
     lora_raw = W.synth_lora(S.SD21_UNET, lseed)
     g = torch.Generator().manual_seed(eseed)

@@ -5,7 +5,7 @@ re-runs the 30-step trajectory of tests/golden/sd21_config1.npz with the HIP eng
 exactly the engine's precision design — and, for f16, the precision class of the reference's own
 `torch_dtype=torch.float16` CUDA run) and reports the distance to the plain fp32 trajectory.  CPU only, ~5 minutes per dtype.
 
-  python tools/emulated_trajectory.py f16 [bf16]
+  python tools/emulated_trajectory.py f16 [bf16] [f16:nores]      (":nores" = residual-stream tensors kept in fp32)
 """
 import os
 import sys
@@ -21,9 +21,9 @@ from oracle import sd21_oracle as O
 
 def main():
     gold = np.load(os.path.join(ROOT, "tests", "golden", "sd21_config1.npz"))
-    useed, vseed, lseed, batch, side, steps, eseed, nseed = gold["meta"].tolist()
+    useed, vseed, lseed, batch, side, steps, eseed, nseed, calibrated = gold["meta"].tolist()
     torch.set_num_threads(os.cpu_count() or 8)
-    usd = W.synth_unet(S.SD21_UNET, useed)
+    usd = W.synth_unet(S.SD21_UNET, useed, calibrated=bool(calibrated))
     merged = O.merge_lora(usd, O.normalize_lora_keys(W.synth_lora(S.SD21_UNET, lseed)))
     g = torch.Generator().manual_seed(eseed)
     pe = torch.randn(batch, 77, 1024, generator=g)
@@ -31,10 +31,11 @@ def main():
     noise = O.draw_noise(torch.Generator().manual_seed(nseed), batch, steps, (side, side))
     ref = gold["latents_per_step"]
     for name in sys.argv[1:] or ["f16"]:
-        dt = torch.float16 if name == "f16" else torch.bfloat16
+        nores = name.endswith(":nores")
+        dt = torch.float16 if name.startswith("f16") else torch.bfloat16
         wsd = {k: (v.to(dt).float() if (v.ndim >= 2 and not k.startswith(("conv_in.", "time_embedding.")) and ".time_emb_proj." not in k)
                    else v) for k, v in merged.items()}
-        O.ROUND = lambda kind, z: z.to(dt).float()
+        O.ROUND = (lambda kind, z: z if kind == "res" else z.to(dt).float()) if nores else (lambda kind, z: z.to(dt).float())
         trace = []
         with torch.no_grad():
             lat = O.sample(wsd, S.SD21_UNET, pe, ne, noise, steps, 5.0, trace=trace)
