@@ -225,6 +225,201 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Loader-wave variant (round 3) for grids of at most ONE workgroup per CU (the whole batch-1 UNet).  In idb_gemm_kernel every
+// wave issues its share of the next stage's LDS-DMA instructions and THEN reads fragments and issues MFMAs; with a lone
+// workgroup per CU nothing hides the ~100 issue cycles of each DMA instruction (4-5 per wave and K-step) nor the counted wait in
+// front of the barrier, and all eight waves go through those phases in lock step: a K-step takes 0.6-1.0 us against 0.13-0.27 us
+// of MFMA time.  Here the workgroup has LW extra waves (one or two per SIMD) that do nothing but the address arithmetic, the
+// DMA issue and the counted vmcnt wait; the 2*WM compute waves keep exactly the fragment mapping, accumulation order and epilogue
+// of idb_gemm_kernel (results are bit-identical) but execute only barrier -> ds_read -> MFMA.  Both roles pass ONE s_barrier per
+// K-step (no flags, no polling: every wave reaches the same nk barriers), the loaders leave after the loop — s_barrier counts only
+// the surviving waves of a workgroup — and the compute waves run the shared epilogue among themselves.
+//   ring: NS stages; at the top of K-step `it` the loaders wait until stage `it` has landed (counted vmcnt: stages it+1 ..
+//   it+NS-2 stay in flight), the barrier publishes it and proves stage it-1 is read, then they issue stage it+NS-1 into that buffer.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int MF, int NF, int NS, int WM, int LW>
+__global__ __launch_bounds__(128 * WM + 64 * LW) void idb_gemm_kernel_lw(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using V8 = typename Op<T>::v8;
+    constexpr int BM = 16 * MF * WM, BN = 32 * NF;
+    constexpr int CT = 128 * WM;                               // compute threads
+    constexpr int LR = 8 * LW;                                 // tile rows per sweep of the loader waves
+    constexpr int NA = BM / LR, NJ = (BN + LR - 1) / LR;       // sweeps per stage: A rows, weight rows (the last may be partial)
+    static_assert(BM % LR == 0, "loader sweep must divide the row tile");
+    constexpr int STAGE = (BM + NJ * LR) * 128;
+    constexpr int LOADS = NA + NJ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 2 * WM;                        // wave-uniform (readfirstlane): a scalar branch, not an EXEC mask
+
+    int wg, kz;
+    if (p.xcd_mode == 0) {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        kz = blockIdx.z;
+    } else {
+        const int X = gridDim.x;
+        const int lin = blockIdx.x + X * blockIdx.z;
+        const int xcd = lin & 7, j = lin >> 3;
+        if (p.xcd_mode == 1) {
+            kz = xcd + 8 * (j / X);
+            wg = j % X;
+        } else {
+            kz = xcd >> 1;
+            wg = (xcd & 1) * (X >> 1) + j;
+        }
+    }
+    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt0 = (int)(((long long)kz * p.ktiles) / p.splitk);
+    const int kt1 = (int)(((long long)(kz + 1) * p.ktiles) / p.splitk);
+    const int nk = kt1 - kt0;
+
+    if (loader) {
+        // ---------------- loader waves: addresses, LDS-DMA issue, counted waits ----------------
+        const int lw = wave - 2 * WM;
+        const int lt = tid - CT;                               // 0 .. 64*LW-1
+        const int lrow = lt >> 3;                              // 0 .. LR-1
+        const unsigned cg16 = ((lt & 7) ^ (lrow & 7)) * 16;    // swizzle on the source side (LR is a multiple of 8)
+        int a_b[NA], a_oy[NA], a_ox[NA];
+        bool a_ok[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + i * LR + lrow;
+            a_ok[i] = m < p.M;
+            const int mm = a_ok[i] ? m : 0;
+            if (p.HW == 1) {
+                a_b[i] = mm;
+                a_oy[i] = a_ox[i] = 0;
+            } else {
+                a_b[i] = mm / p.HW;
+                const int rem = mm - a_b[i] * p.HW;
+                a_oy[i] = rem / p.OW;
+                a_ox[i] = rem - a_oy[i] * p.OW;
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
+        unsigned w_voff[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + j * LR + lrow;
+            w_voff[j] = (n < p.N && j * LR + lrow < BN) ? (unsigned)(n >> 4) * p.w_blk_bytes + (unsigned)(n & 15) * p.w_row_bytes + cg16 : IDB_OOB;
+        }
+        unsigned w_soff = (unsigned)kt0 * p.w_kstep;
+        int s = 0, tap = 0, c0 = 0, cur_c = 64, tap_end = 9;
+        {
+            int rem = kt0;
+            while (s < IDB_MAX_SRC - 1) {
+                const int steps = p.src[s].taps * (p.src[s].C >> 6);
+                if (rem < steps) break;
+                rem -= steps;
+                ++s;
+            }
+            const int cs = p.src[s].C >> 6;
+            if (p.src[s].taps == 9) {
+                tap = rem / cs;
+                c0 = (rem - tap * cs) << 6;
+            } else {
+                tap = 4;
+                c0 = rem << 6;
+            }
+        }
+        __amdgpu_buffer_rsrc_t rs_a = rs_w;
+        unsigned a_voff[NA];
+        bool need_retap = true;
+        auto stage = [&](int buf) {
+            char* sA = smem + buf * STAGE;
+            char* sB = sA + BM * 128;
+            if (need_retap) {
+                const GemmSrcK S = p.src[s];
+                rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)S.ptr, 0, S.bytes, IDB_RSRC_FLAGS);
+                cur_c = S.C;
+                tap_end = S.taps == 9 ? 9 : 5;
+                const int t3 = tap / 3;
+                const int dy = t3 - p.pad, dx = tap - t3 * 3 - p.pad;
+                const int LH = S.H << S.up, LWd = S.W << S.up;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
+                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LWd;
+                    const int pix = (a_b[i] * S.H + (iy >> S.up)) * S.W + (ix >> S.up);
+                    a_voff[i] = ok ? (unsigned)pix * (unsigned)(S.C * 2) + cg16 : IDB_OOB;
+                }
+                need_retap = false;
+            }
+            const unsigned a_soff = (unsigned)c0 * 2u;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(sA + (i * 64 * LW + lw * 64) * 16), 16, a_voff[i], a_soff, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * 64 * LW + lw * 64) * 16), 16, w_voff[j], w_soff, 0, 0);
+            w_soff += p.w_kstep;
+            c0 += 64;
+            if (c0 == cur_c) {
+                c0 = 0;
+                need_retap = true;
+                if (++tap == tap_end) {
+                    if (s < IDB_MAX_SRC - 1) ++s;
+                    tap = p.src[s].taps == 9 ? 0 : 4;
+                }
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st)
+            if (st < nk) stage(st);
+        int cur = 0;
+        for (int it = 0; it < nk; ++it) {
+            if (it + NS - 2 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * LOADS) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (it + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1);
+            cur = cur + 1 == NS ? 0 : cur + 1;
+        }
+        return;                                                // s_barrier counts the surviving waves only
+    }
+
+    // ---------------- compute waves: the fragment mapping and the epilogue of idb_gemm_kernel ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float2 ln_part = make_float2(0.f, 0.f);
+    if (p.ln_stats) ln_part = idb_ln_row_partials<BM, CT>(p, m0, tid);
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+        // lgkmcnt(0): this wave's fragment reads of the previous stage have returned before the loaders may overwrite its buffer
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
+        const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pos = ((ks * 4 + fg) ^ (fr & 7)) * 16;
+            V8 af[MF], wf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const V8*)(sA + i * 16 * 128 + pos);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *(const V8*)(sB + j * 16 * 128 + pos);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
+        }
+        cur = cur + 1 == NS ? 0 : cur + 1;
+    }
+    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, kz, p.ln_stats != nullptr, ln_part);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Register-staged variant: identical tiling, addressing and epilogue, but the operands go HBM/L2 -> VGPR
 // (buffer_load_dwordx4, asynchronous until its first use) -> LDS (ds_write_b128 after the MFMAs of the current
@@ -709,8 +904,14 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     pl->ktiles = (int)(K / 64);
     int tile = d->tile % 10, ring3 = d->tile / 10;     // ring3: 0 -> 2-stage, 1 -> 3-stage, 2 -> 4-stage LDS ring
     // ring3: 0 -> 2-stage LDS-DMA ring, 1 -> 3-stage, 2 -> 4-stage, 3 -> register-staged double buffer, 4 -> persistent (plain matrices)
-    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 4 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
-                    !(ring3 == 4 && tile > 2) && !(ring3 > 1 && (tile >= 6 || tile == 4)), "idb_gemm: tile id out of range");
+    // 5 / 6 / 7 -> loader-wave variant (idb_gemm_kernel_lw): 4 loader waves + 3-stage ring / 8 loader waves + 3 stages / 4 loader waves + 4 stages
+    // 8 -> loader-wave variant with TWICE the rows (shapes 8 / 9 only: 256x160 / 256x128, 8 MFMA waves + 4 loader waves, 3-stage ring, one
+    //      workgroup per CU with all 160 KB of LDS): 97 / 85 FLOP per byte moved L2 -> LDS instead of 73 for large grids
+    const bool lw_tile = tile == 4 || (tile >= 6 && tile <= 9);
+    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 8 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
+                    !(ring3 == 4 && tile > 2) && !(ring3 > 1 && ring3 < 5 && (tile >= 6 || tile == 4)) && !(ring3 >= 5 && !lw_tile) &&
+                    !(ring3 == 8 && tile < 8),
+                "idb_gemm: tile id out of range");
     const bool plain = d->nsrc == 1 && d->src[0].taps == 1 && d->src[0].in_h == 1 && d->src[0].in_w == 1;
     const bool pl_ok = plain && d->split_k <= 1 && d->out_dtype == d->dtype && (d->geglu ? d->n / 2 : d->n) % 4 == 0 &&
                        d->out_ld % 4 == 0 && M * d->out_ld * 2 < (1LL << 31);
@@ -785,8 +986,24 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         static const int env_plg = [] { const char* e = getenv("IDB_GEMM_PL_GEGLU_TILES"); return e ? atoi(e) : 512; }();
         if (env_pl && pl_ok && d->geglu && tile == 9 && env_plg > 0 && tiles >= env_plg && d->split_k <= 1) { tile = 2; ring3 = 4; }
     }
+    if (d->tile == 0 && ring3 == 1 && (tile == 4 || (tile >= 6 && tile <= 9))) {
+        // one workgroup per CU (ring-3 plans): loader waves take the DMA issue and the waits off the MFMA waves (idb_gemm_kernel_lw)
+        // measured (tools/bench_lw.py, B_eff 2, cold weights in a HIP graph): conv 320->320 @64x64 31.3 -> 23.7 us, the other convs of the
+        // 64x64 / 32x32 levels -5...-10 %, weight-streaming 16x16 / 8x8 layers and short-K linears 0...-3 %; 4 loader waves with a
+        // 4-stage ring (7) >= 4 with 3 stages (5) >= 8 with 3 stages (6); end to end batch 1 +1.1 %.  IDB_GEMM_LW=0: ring-3 kernels
+        static const int env_lw = [] { const char* e = getenv("IDB_GEMM_LW"); return e ? atoi(e) : 7; }();
+        if (env_lw >= 5 && env_lw <= 7) ring3 = env_lw;
+    }
+    if (d->tile == 0 && ring3 == 0 && (tile == 8 || tile == 9) && !d->geglu && pl->ktiles >= 20) {
+        // large grids, K >= 1280: 256-row loader-wave tiles once the 256-row grid is still >= IDB_GEMM_BIG_TILES workgroups (two rounds of
+        // the chip; 0 = off).  Measured at B_eff 128 (tools/bench_conv.py / bench_proj.py): every 3x3 conv +8...+19 % (1.01-1.17 ->
+        // 1.08-1.32 PFLOP/s), K >= 1280 projections +3...+15 %, K = 640 equal, K = 320 -19 % (excluded); batch 64 end to end +4.1 %
+        static const int env_big = [] { const char* e = getenv("IDB_GEMM_BIG_TILES"); return e ? atoi(e) : 512; }();
+        const long long blocks256 = ((M + 255) / 256) * ((d->n + 32 * kTiles[tile].nf - 1) / (32 * kTiles[tile].nf));
+        if (env_big > 0 && blocks256 >= env_big) ring3 = 8;
+    }
     pl->tile = tile + 10 * ring3;
-    const int bm = 16 * kTiles[tile].mf * kTiles[tile].wm, bn = 32 * kTiles[tile].nf;
+    const int bm = 16 * kTiles[tile].mf * kTiles[tile].wm * (ring3 == 8 ? 2 : 1), bn = 32 * kTiles[tile].nf;
     pl->tiles_m = (int)((M + bm - 1) / bm);
     pl->tiles_n = (d->n + bn - 1) / bn;
     const long long blocks = (long long)pl->tiles_m * pl->tiles_n;
@@ -794,7 +1011,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     int sk = d->split_k;
     if (sk <= 0) {
         sk = 1;
-        const bool small_tile = kTiles[tile].mf * kTiles[tile].wm <= 4;     // 64-row tiles
+        const bool small_tile = kTiles[tile].mf * kTiles[tile].wm <= 4 && ring3 != 8;     // 64-row tiles
         if (auto_sk) {
             sk = auto_sk;
         } else if (!d->geglu && small_tile && blocks < 96 && pl->ktiles >= 10) {
@@ -818,7 +1035,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     if (d->act) sk = 1;
     if (sk > pl->ktiles) sk = pl->ktiles;
     if (sk < 1) sk = 1;
-    if (d->split_k <= 0 && !(d->flags & 16) && pl->tile / 10 <= 1 && kTiles[tile].wm == 4) {
+    if (d->split_k <= 0 && !(d->flags & 16) && (pl->tile / 10 <= 1 || pl->tile / 10 >= 5) && kTiles[tile].wm == 4) {
         // one K-slice per XCD (kernel remap modes 1/2) needs S % 8 == 0 or S == 4: round the heuristic's choice
         static const int env_xcd = [] { const char* e = getenv("IDB_GEMM_XCD_SLICES"); return e ? atoi(e) : 1; }();
         if (env_xcd) {
@@ -853,6 +1070,38 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
     hipLaunchKernelGGL((idb_gemm_kernel<T, MF, NF, NS, WM>), grid, dim3(128 * WM), LDS, st, p);
     IDB_CHECK_LAUNCH("idb_gemm");
     return IDB_OK;
+}
+
+template <typename T, int MF, int NF, int NS, int WM, int LW>
+int launch_tile_lw(const GemmParams& p, const Plan& pl, hipStream_t st) {
+    constexpr int LR = 8 * LW, NJ = (32 * NF + LR - 1) / LR;
+    constexpr int LDS = (16 * MF * WM + NJ * LR) * 128 * NS;
+    static_assert(LDS <= 160 * 1024, "LDS ring does not fit");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_gemm_kernel_lw<T, MF, NF, NS, WM, LW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            idb_set_error("idb_gemm: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
+            return IDB_EHIP;
+        }
+        attr_done = true;
+    }
+    dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.splitk);
+    hipLaunchKernelGGL((idb_gemm_kernel_lw<T, MF, NF, NS, WM, LW>), grid, dim3(128 * WM + 64 * LW), LDS, st, p);
+    IDB_CHECK_LAUNCH("idb_gemm(lw)");
+    return IDB_OK;
+}
+
+template <typename T, int NS, int LW>
+int launch_lw_by_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
+    switch (pl.tile % 10) {
+        case 4: return launch_tile_lw<T, 1, 2, NS, 4, LW>(p, pl, st);
+        case 6: return launch_tile_lw<T, 1, 5, NS, 4, LW>(p, pl, st);
+        case 7: return launch_tile_lw<T, 1, 4, NS, 4, LW>(p, pl, st);
+        case 8: return launch_tile_lw<T, 2, 5, NS, 4, LW>(p, pl, st);
+        default: return launch_tile_lw<T, 2, 4, NS, 4, LW>(p, pl, st);
+    }
 }
 
 template <typename T, int MF, int NF>
@@ -896,6 +1145,15 @@ int launch_tile_pl(const GemmParams& p, const Plan& pl, hipStream_t st) {
 template <typename T>
 int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
     int rc;
+    if (pl.tile / 10 >= 5) {
+        if (pl.tile / 10 == 8)
+            rc = pl.tile % 10 == 8 ? launch_tile_lw<T, 4, 5, 3, 4, 4>(p, pl, st) : launch_tile_lw<T, 4, 4, 3, 4, 4>(p, pl, st);
+        else
+            rc = pl.tile / 10 == 5 ? launch_lw_by_tile<T, 3, 4>(p, pl, st) : pl.tile / 10 == 6 ? launch_lw_by_tile<T, 3, 8>(p, pl, st)
+                                                                                               : launch_lw_by_tile<T, 4, 4>(p, pl, st);
+        if (rc != IDB_OK || (d->flags & 1)) return rc;
+        return idb_finish_splitk<T>(p, pl.M, d->n, d->batch, pl.splitk, d->gn_partials, d->gn_groups, d->dtype, st);
+    }
     switch (pl.tile) {
         case 1: rc = launch_tile<T, 4, 5, 2>(p, pl, st); break;
         case 2: rc = launch_tile<T, 4, 4, 2>(p, pl, st); break;
@@ -957,9 +1215,9 @@ static bool gemm_folds_ln(const idb_gemm_desc* d, const Plan& pl) {
 
 // the GEMM's own LDS-staged epilogue can emit the first GroupNorm pass of the output (no split-K, whole groups per column tile)
 static bool gemm_epilogue_emits_gn(const idb_gemm_desc* d, const Plan& pl, int groups) {
-    if (pl.tile / 10 > 2 || d->geglu || !gemm_uses_lds_epilogue(d, pl)) return false;
+    if ((pl.tile / 10 > 2 && pl.tile / 10 < 5) || d->geglu || !gemm_uses_lds_epilogue(d, pl)) return false;
     const TileCfg& t = kTiles[pl.tile % 10];
-    return idb_epilogue_emits_gn(16 * t.mf * t.wm, 32 * t.nf, 128 * t.wm, pl.M, d->n, groups) && (long long)d->out_h * d->out_w % 64 == 0 &&
+    return idb_epilogue_emits_gn(16 * t.mf * t.wm * (pl.tile / 10 == 8 ? 2 : 1), 32 * t.nf, 128 * t.wm, pl.M, d->n, groups) && (long long)d->out_h * d->out_w % 64 == 0 &&
            d->out_ld == d->n;
 }
 
@@ -1028,7 +1286,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
         static const int env_xcd = [] { const char* e = getenv("IDB_GEMM_XCD_SLICES"); return e ? atoi(e) : 1; }();
         const long long X = (long long)pl.tiles_m * pl.tiles_n;
         p.xcd_mode = 0;
-        if (env_xcd && pl.tile / 10 <= 1 && pl.tile % 10 != 5 && pl.tile % 10 != 0) {
+        if (env_xcd && (pl.tile / 10 <= 1 || pl.tile / 10 >= 5) && pl.tile % 10 != 5 && pl.tile % 10 != 0) {
             if (pl.splitk >= 8 && pl.splitk % 8 == 0) p.xcd_mode = 1;
             else if (pl.splitk == 4 && X % 2 == 0) p.xcd_mode = 2;
         }

@@ -14,6 +14,10 @@ config1 : BASELINE configs[1] = the headline workload: SD-2.1-base shapes + rank
        the 30 steps, final latents, decoded uint8 image, and eps (uncond, cond) of the steps in EPS_STEPS for the
        teacher-forced per-step comparison.  CALIBRATED synthetic weights (weights.calibrate_unet: eps = x_t + a network-dependent
        correction, latents stay O(1) over the 30 steps like a trained model's; meta[8] = 1)
+config4 : BASELINE configs[4] geometry on the calibrated network: 96x96 latents (768x768), v-prediction, rank-4 LoRA, 10 DDPM steps,
+       CFG 5.0, batch 1 -> sd21_config4_vpred.npz: fp32 oracle latents after each step + decoded image, AND the same trajectory from
+       the oracle with the fp8 engine's quantisation emulated (e4m3 resnet-conv operands, f16 storage elsewhere): the error CLASS the
+       fp8 path is held to (tests/test_fp8_path_gpu.py)
 batch3 : three distinct work items (prompt embeddings and initial latents) of the calibrated configs[1] network, ONE CFG forward at
        t = timesteps[0]: eps (uncond, cond) -> sd21_batch3_eps.npz — the oracle side of the batch-64 teacher-forced test
 """
@@ -83,6 +87,52 @@ def main():
         print("config1: final latents std", d["final_latents"].std(), "max", np.abs(d["final_latents"]).max(),
               "image mean", d["image_u8"].mean(), "per-step std", d["latents_per_step"].std(axis=(1, 2, 3, 4)).round(3),
               "per-step max", np.abs(d["latents_per_step"]).max(axis=(1, 2, 3, 4)).round(2))
+    if "config4" in what:
+        torch.set_num_threads(os.cpu_count() or 8)
+        ucfg, vcfg = S.SD21_UNET, S.SD21_VAE
+        usd, vsd = W.synth_unet(ucfg, 1234, calibrated=True), W.synth_vae(vcfg, 1235)
+        lora = O.normalize_lora_keys(W.synth_lora(ucfg, 1))
+        merged = O.merge_lora(usd, lora)
+        sched = S.SchedulerConfig(prediction_type="v_prediction")
+        steps, side = 10, 96
+        g = torch.Generator().manual_seed(2024)
+        pe = torch.randn(1, 77, ucfg.cross_attention_dim, generator=g)
+        ne = torch.randn(1, 77, ucfg.cross_attention_dim, generator=g)
+        noise = O.draw_noise(torch.Generator().manual_seed(0), 1, steps, (side, side))
+        tr = []
+        with torch.no_grad():
+            lat = O.sample(merged, ucfg, pe, ne, noise, steps, 5.0, sched=sched, trace=tr)
+            img = O.to_uint8(O.decode_to_images(vsd, vcfg, lat).clone())
+            # the fp8 engine's rounding points: e4m3 weights / GroupNorm+SiLU outputs of the UNet resnets, f16 everywhere else
+            q = O.fp8_weights(merged)
+            wsd = {k: (v.half().float() if (v.ndim >= 2 and not k.startswith(("conv_in.", "time_embedding.")) and ".time_emb_proj." not in k) else v)
+                   for k, v in q.items()}
+            for k, v in q.items():
+                if ".resnets." in k and k.endswith((".conv1.weight", ".conv2.weight")):
+                    wsd[k] = v
+            O.ROUND = lambda kind, z: z.half().float()
+            O.ROUND_CONV_IN = O.fp8_quantize
+            try:
+                tr8 = []
+                lat8 = O.sample(wsd, ucfg, pe, ne, noise, steps, 5.0, sched=sched, trace=tr8)
+            finally:
+                O.ROUND, O.ROUND_CONV_IN = None, None
+            img8 = O.to_uint8(O.decode_to_images(vsd, vcfg, lat8).clone())
+        ref_steps, emu_steps = torch.stack([t[2] for t in tr]).numpy(), torch.stack([t[2] for t in tr8]).numpy()
+        cls = [(np.sqrt(((emu_steps[i].astype(np.float64) - ref_steps[i]) ** 2).mean()) / ref_steps[i].std(),
+                np.abs(emu_steps[i].astype(np.float64) - ref_steps[i]).max()) for i in range(steps)]
+        dimg = img8.numpy().astype(np.float64) - img.numpy().astype(np.float64)
+        d = {"latents_per_step": ref_steps, "final_latents": lat.numpy(), "image_u8": img.numpy(),
+             # the emulated-quantisation trajectory is kept as its error figures + final latents only (fixture size)
+             "emulated_fp8_error_per_step": np.array(cls, dtype=np.float64), "emulated_fp8_final_latents": emu_steps[-1],
+             "emulated_fp8_image_psnr": np.float64(10 * np.log10(255.0 ** 2 / (dimg ** 2).mean())),
+             "timesteps": np.array(O.ddpm_timesteps(steps)), "noise_first4": noise.flatten()[:4].numpy(),
+             "meta": np.array([1234, 1235, 1, 1, side, steps, 2024, 0, 1]),
+             "unet_fingerprint": weight_fingerprint(usd, fp + ["conv_out.weight", "conv_in.weight"])}
+        np.savez_compressed(os.path.join(HERE, "sd21_config4_vpred.npz"), **d)
+        e = np.abs(d["emulated_fp8_final_latents"] - d["final_latents"])
+        print("config4: final latents std", d["final_latents"].std(), "max", np.abs(d["final_latents"]).max(), "| emulated-fp8 vs fp32: max-abs",
+              e.max(), "rel-RMS", np.sqrt((e ** 2).mean()) / np.sqrt((d["final_latents"] ** 2).mean()))
     if "batch3" in what:
         torch.set_num_threads(os.cpu_count() or 8)
         ucfg = S.SD21_UNET

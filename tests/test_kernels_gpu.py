@@ -582,3 +582,91 @@ def test_ln_fold_vectors(eng, rows, cols, rank, geglu):
     v_ref = (merged @ beta.double())[perm] + bias.double()
     assert (u.double() - u_ref).abs().max().item() < 2e-5 * max(1.0, u_ref.abs().max().item())
     assert (v.double() - v_ref).abs().max().item() < 2e-5 * max(1.0, v_ref.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------------
+# loader-wave variant (idb_gemm_kernel_lw: tile ids 5x / 6x / 7x): same fragment mapping and accumulation order as the ring-3
+# kernels of the same tile, so outputs must be BIT-IDENTICAL — over ragged M / N, split-K, conv taps, strides, upsampling,
+# K-segment concatenation, folded LayerNorm and the GroupNorm-statistics epilogue
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [5, 6, 7])
+@pytest.mark.parametrize("m,n,k,shape,split_k", [
+    (256, 320, 320, 6, 1), (300, 128, 64, 7, 1), (700, 640, 1280, 6, 3), (513, 250, 704, 9, 2), (1000, 480, 192, 8, 2),
+    (70, 640, 1280, 9, 5), (130, 160, 192, 8, 1), (77, 256, 1024, 4, 3), (8192, 320, 2880, 6, 1), (128, 1280, 11520, 7, 16),
+    (2048, 640, 5760, 8, 4), (64, 64, 64, 4, 1)])
+def test_gemm_loader_waves_bit_identical(eng, variant, m, n, k, shape, split_k):
+    a = _rand((m, k), 51).to(eng.tdt)
+    w = _rand((n, k), 52, k ** -0.5).to(eng.tdt)
+    bias = _rand((n,), 53)
+    res = _rand((m, n), 54).to(eng.tdt) if n % 8 == 0 else None
+    ref = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, m, 1, 1, bias=bias, residual=res, tile=10 + shape, split_k=split_k)
+    out = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, m, 1, 1, bias=bias, residual=res, tile=10 * variant + shape, split_k=split_k)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    _check(out, a.float() @ w.float().t() + bias + (res.float() if res is not None else 0), _tol(eng), "lw linear")
+    wt = eng.tile_weight(w)
+    out_t = eng.gemm([(a, k, 1, 1, 1, 0)], wt, n, m, 1, 1, bias=bias, residual=res, tile=10 * variant + shape, split_k=split_k)
+    torch.cuda.synchronize()
+    assert torch.equal(out_t, ref)
+
+
+@pytest.mark.parametrize("variant", [5, 6, 7])
+@pytest.mark.parametrize("b,h,w_,cin,cout,stride,up,shape", [
+    (2, 16, 16, 64, 128, 1, 0, 7), (2, 13, 11, 64, 320, 1, 0, 6), (1, 32, 32, 320, 320, 1, 0, 8), (2, 16, 16, 64, 64, 2, 0, 7),
+    (1, 8, 8, 128, 160, 1, 1, 6), (2, 9, 7, 64, 128, 2, 0, 9), (3, 8, 8, 192, 64, 1, 0, 4)])
+def test_conv_loader_waves_bit_identical(eng, variant, b, h, w_, cin, cout, stride, up, shape):
+    x = _rand((b, h, w_, cin), 61).to(eng.tdt)
+    wc = _rand((cout, cin, 3, 3), 62, (9 * cin) ** -0.5)
+    w = eng._pack_conv(wc)
+    bias = _rand((cout,), 63)
+    oh, ow = ((h << up) + stride - 1) // stride, ((w_ << up) + stride - 1) // stride
+    ref = eng.gemm([(x, cin, 9, h, w_, up)], w, cout, b, oh, ow, bias=bias, stride=stride, tile=10 + shape)
+    out = eng.gemm([(x, cin, 9, h, w_, up)], w, cout, b, oh, ow, bias=bias, stride=stride, tile=10 * variant + shape)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    xin = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest") if up else x.float().permute(0, 3, 1, 2)
+    want = F.conv2d(xin, wc.to(eng.tdt).float(), bias, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    _check(out, want, _tol(eng), "lw conv")
+
+
+def test_resnet_conv2_with_shortcut_loader_waves(eng):
+    """conv2 + 1x1 shortcut over a skip concatenation as ONE GEMM with three K segments, plus the GroupNorm-statistics epilogue."""
+    b, h, c1, c2, cout = 2, 16, 128, 64, 320
+    n2 = _rand((b, h, h, cout), 71).to(eng.tdt)
+    xa, xb = _rand((b, h, h, c1), 72).to(eng.tdt), _rand((b, h, h, c2), 73).to(eng.tdt)
+    w = _rand((cout, 9 * cout + c1 + c2), 74, (9 * cout) ** -0.5).to(eng.tdt)
+    bias = _rand((cout,), 75)
+    srcs = [(n2, cout, 9, h, h, 0), (xa, c1, 1, h, h, 0), (xb, c2, 1, h, h, 0)]
+    ref = eng.gemm(srcs, w, cout, b, h, h, bias=bias, tile=16, gn_stats=32)
+    out = eng.gemm(srcs, w, cout, b, h, h, bias=bias, tile=56, gn_stats=32)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert (getattr(ref, "_gn", None) is None) == (getattr(out, "_gn", None) is None)
+    if getattr(ref, "_gn", None) is not None:
+        assert torch.equal(ref._gn[0], out._gn[0])
+
+
+@pytest.mark.parametrize("m,n,k,shape,split_k", [(4096, 320, 320, 8, 1), (1000, 480, 704, 8, 1), (700, 256, 1280, 9, 2), (513, 250, 192, 9, 1),
+                                                 (256, 160, 64, 8, 1), (5000, 640, 2560, 8, 3)])
+def test_gemm_256_row_loader_wave_tiles_bit_identical(eng, m, n, k, shape, split_k):
+    """tile ids 88 / 89: 256x160 / 256x128 with 8 MFMA waves + 4 loader waves, one workgroup per CU (all 160 KB of LDS)."""
+    a = _rand((m, k), 81).to(eng.tdt)
+    w = eng.tile_weight(_rand((n, k), 82, k ** -0.5).to(eng.tdt))
+    bias = _rand((n,), 83)
+    res = _rand((m, n), 84).to(eng.tdt) if n % 8 == 0 else None
+    ref = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, m, 1, 1, bias=bias, residual=res, tile=shape, split_k=split_k)
+    out = eng.gemm([(a, k, 1, 1, 1, 0)], w, n, m, 1, 1, bias=bias, residual=res, tile=80 + shape, split_k=split_k)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
+def test_conv_256_row_loader_wave_tile_bit_identical_with_gn_partials(eng):
+    b, h, cin, cout = 4, 32, 128, 320
+    x = _rand((b, h, h, cin), 91).to(eng.tdt)
+    w = eng.tile_weight(eng._pack_conv(_rand((cout, cin, 3, 3), 92, (9 * cin) ** -0.5)))
+    bias = _rand((cout,), 93)
+    ref = eng.gemm([(x, cin, 9, h, h, 0)], w, cout, b, h, h, bias=bias, tile=8, gn_stats=32)
+    out = eng.gemm([(x, cin, 9, h, h, 0)], w, cout, b, h, h, bias=bias, tile=88, gn_stats=32)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert getattr(out, "_gn", None) is not None and torch.allclose(ref._gn[0], out._gn[0], rtol=1e-5, atol=1e-3)

@@ -75,11 +75,16 @@ def test_detect_api_and_align_crop(det):
     m, w = det
     img = _images(seed=4)
     boxes, probs, landmarks = m.detect(img, landmarks=True)
-    assert boxes.shape == (2,) and landmarks[0].shape == (1, 5, 2) and boxes[0].shape == (1, 4) and probs[0].shape == (1,)
+    # upstream detect() returns EVERY face of an image, largest first with select_largest (keep_all only acts in forward());
+    # the reference takes landmark[0]
+    assert boxes.shape == (2,) and landmarks[0].shape[1:] == (5, 2) and boxes[0].shape[1:] == (4,) and probs[0].shape == (boxes[0].shape[0],)
     b_ref, i_ref, p_ref = O.detect_face(img, w)
     for k in range(2):
         bb, pp, ll = O.select_largest_first(b_ref, i_ref, p_ref, k)
-        assert np.abs(boxes[k] - bb.numpy()).max() < 1e-2 and np.abs(landmarks[k] - ll.numpy()).max() < 1e-2
+        assert boxes[k].shape[0] == int((i_ref == k).sum())
+        area = (boxes[k][:, 2] - boxes[k][:, 0]) * (boxes[k][:, 3] - boxes[k][:, 1])
+        assert (np.diff(area) <= 0).all()
+        assert np.abs(boxes[k][:1] - bb.numpy()).max() < 1e-2 and np.abs(landmarks[k][:1] - ll.numpy()).max() < 1e-2
     blank = torch.zeros(1, 64, 64, 3, dtype=torch.uint8)
     b0, p0, l0 = m.detect(blank, landmarks=True)
     # (a blank image may or may not yield candidates with synthetic weights; the call must return one entry per image)
