@@ -37,15 +37,18 @@ PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI
 _TILE_SHAPES = {1: "128x160", 2: "128x128", 3: "64x160", 4: "64x64,8w", 5: "128x32",
                 6: "64x160,8w", 7: "64x128,8w", 8: "128x160,8w", 9: "128x128,8w"}
 _TILE_VARIANTS = {0: "idb_gemm_kernel<{},ring2>", 1: "idb_gemm_kernel<{},ring3>", 2: "idb_gemm_kernel<{},ring4>",
-                  3: "idb_gemm_kernel_rs<{}>", 4: "idb_gemm_kernel_pl<{}>"}
+                  3: "idb_gemm_kernel_rs<{}>", 4: "idb_gemm_kernel_pl<{}>", 5: "idb_gemm_kernel_lw<{},4 loader waves,ring3>",
+                  6: "idb_gemm_kernel_lw<{},8 loader waves,ring3>", 7: "idb_gemm_kernel_lw<{},4 loader waves,ring4>",
+                  8: "idb_gemm_kernel_lw<{},4 loader waves,ring3>"}
 
 
 class _TileNames(dict):
-    """idb_gemm_plan tile id -> kernel instance name (id = shape + 10 * variant, see idb_gemm.hip); 104 / 105 = idb_hconv_kernel."""
+    """idb_gemm_plan tile id -> kernel instance name (id = shape + 10 * variant, see idb_gemm.hip)."""
     def __missing__(self, t):
-        if t >= 100:
-            return f"idb_hconv_kernel<128x{32 * (t - 100)},8w>"
-        return _TILE_VARIANTS[t // 10].format(_TILE_SHAPES[t % 10])
+        shape = _TILE_SHAPES[t % 10]
+        if t // 10 == 8:                                   # the 256-row loader-wave tiles
+            shape = shape.replace("128x", "256x", 1)
+        return _TILE_VARIANTS[t // 10].format(shape)
 
 
 TILE_NAMES = _TileNames()
@@ -165,7 +168,7 @@ def kernel_roofline(eng, batch, lat_side, n_ctx):
     for e in log:
         e["desc"].flags = 1
         e["ev"] = []
-        e["fn"] = eng.lib.idb_hconv if e.get("hconv") else eng.lib.idb_gemm
+        e["fn"] = eng.lib.idb_gemm
     empty = []
     for r in range(REPS + 1):                                            # pass 0 = warm-up, untimed
         for e in log:
@@ -225,14 +228,15 @@ _KTILES = {1: (4, 5, 2), 2: (4, 4, 2), 3: (2, 5, 2), 4: (1, 2, 4), 5: (4, 1, 2),
 def mangled_gemm_name(tile: int, dtype: str) -> str:
     """Kernel symbol of an idb_gemm_plan tile id as rocprofv3 -M lists it (idb_gemm.hip: kTiles, launch_all)."""
     t = "DF16b" if dtype == "bf16" else "DF16_"
-    if tile >= 100:
-        return f"idb_hconv_kernelI{t}Li{tile - 100}EE"
     mf, nf, wm = _KTILES[tile % 10]
     v = tile // 10
     if v == 3:
         return f"idb_gemm_kernel_rsI{t}Li{mf}ELi{nf}EE"
     if v == 4:
         return f"idb_gemm_kernel_plI{t}Li{mf}ELi{nf}EE"
+    if v >= 5:                                             # idb_gemm_kernel_lw<T, MF, NF, NS, WM, LW>
+        ns, lw = {5: (3, 4), 6: (3, 8), 7: (4, 4), 8: (3, 4)}[v]
+        return f"idb_gemm_kernel_lwI{t}Li{mf * (2 if v == 8 else 1)}ELi{nf}ELi{ns}ELi{wm}ELi{lw}EE"
     return f"idb_gemm_kernelI{t}Li{mf}ELi{nf}ELi{v + 2}ELi{wm}EE"
 
 

@@ -22,7 +22,6 @@ EXPORTS = [
     "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm_row_stats_tiles", "idb_gemm_folds_layernorm", "idb_gemm_emits_gn_partials", "idb_gemm",
     "idb_pack_conv_weight", "idb_pack_matrix", "idb_tiled_weight_bytes", "idb_tile_weight", "idb_lora_merge", "idb_lora_merge_scaled", "idb_pack_matrix_scaled", "idb_ln_fold_vectors",
     "idb_groupnorm_workspace_bytes", "idb_groupnorm", "idb_layernorm", "idb_groupnorm_stats",
-    "idb_hconv_workspace_bytes", "idb_hconv_plan", "idb_hconv",
     "idb_attention", "idb_embed_tokens", "idb_softmax_rows",
     "idb_timestep_sinusoid", "idb_linear_f32", "idb_conv_in",
     "idb_cfg_ddpm_step", "idb_postprocess",
@@ -48,20 +47,6 @@ class GemmDesc(C.Structure):
                 ("counters", C.c_void_p), ("counters_len", C.c_int32), ("gn_partials", C.c_void_p), ("gn_groups", C.c_int32),
                 ("row_stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_tiles", C.c_int32), ("ln_u", C.c_void_p),
                 ("ln_v", C.c_void_p), ("ln_eps", C.c_float), ("pad_mode", C.c_int32), ("w_layout", C.c_int32)]
-
-
-class HconvSeg(C.Structure):
-    _fields_ = [("x0", C.c_void_p), ("c0", C.c_int32), ("x1", C.c_void_p), ("c1", C.c_int32), ("taps", C.c_int32)]
-
-
-class HconvDesc(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("n", C.c_int32),
-                ("nseg", C.c_int32), ("seg", HconvSeg * 2),
-                ("gn_partials", C.c_void_p), ("gn_chunks", C.c_int32), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
-                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("silu", C.c_int32),
-                ("w_ptr", C.c_void_p), ("bias", C.c_void_p), ("sample_bias", C.c_void_p), ("sample_bias_ld", C.c_int32),
-                ("residual", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int32), ("split_k", C.c_int32),
-                ("gn_partials_out", C.c_void_p), ("gn_groups_out", C.c_int32), ("flags", C.c_int32)]
 
 
 class GemmFp8Desc(C.Structure):
@@ -112,9 +97,6 @@ def load() -> C.CDLL:
         "idb_groupnorm": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp, sz, vp, i32, vp, i32, vp]),
         "idb_layernorm": (C.c_int, [vp, vp, i64, i32, f32, vp, vp, i32, vp]),
         "idb_groupnorm_stats": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp, sz, C.POINTER(i32), i32, vp]),
-        "idb_hconv_workspace_bytes": (sz, [C.POINTER(HconvDesc)]),
-        "idb_hconv_plan": (C.c_int, [C.POINTER(HconvDesc), C.POINTER(i32), C.POINTER(i32)]),
-        "idb_hconv": (C.c_int, [C.POINTER(HconvDesc), vp, sz, vp]),
         "idb_attention": (C.c_int, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp]),
         "idb_embed_tokens": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "idb_softmax_rows": (C.c_int, [vp, i64, i32, i32, vp]),

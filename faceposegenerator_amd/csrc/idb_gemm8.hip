@@ -16,6 +16,7 @@
 //   * the block scales of the MX instruction are fixed at 1.0 (E8M0 127); the real scales — one per tensor for the activations,
 //     one per output channel for the weights — multiply the fp32 accumulator in the epilogue.
 #include "idb_gemm_epi.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -177,6 +178,157 @@ __global__ __launch_bounds__(512, 2) void idb_gemm8_kernel(const Gemm8Params p8)
 #endif
 }
 
+
+// Loader-wave form (round 3), the fp8 twin of idb_gemm_kernel_lw: LW extra waves do the address arithmetic, the LDS-DMA issue and the
+// counted waits; the 8 MFMA waves run barrier -> ds_read -> MFMA only, with the same fragment mapping, accumulation order and epilogue
+// (bit-identical outputs).  One s_barrier per K-step for both roles, loaders leave after the loop.  Used as a 256-row tile
+// (MF = 4: 256x160 / 256x128, 3-stage ring = all 160 KB of LDS, one workgroup per CU) for large grids.
+template <typename T, int MF, int NF, int NS, int LW>
+__global__ __launch_bounds__(512 + 64 * LW) void idb_gemm8_kernel_lw(const Gemm8Params p8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const GemmParams& p = p8.g;
+    constexpr int WM = 4, BM = 16 * MF * WM, BN = 32 * NF, CT = 512, LR = 8 * LW;
+    constexpr int NA = BM / LR, NJ = (BN + LR - 1) / LR, STAGE = (BM + NJ * LR) * 128, LOADS = NA + NJ;
+    static_assert(BM % LR == 0, "loader sweep must divide the row tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = p.ktiles;
+
+    if (wave >= 8) {                                       // ---------------- loader waves ----------------
+        const int lw = wave - 8, lt = tid - CT, lrow = lt >> 3;
+        const int chunk = (lt & 7) ^ (lrow & 7);
+        const unsigned cg16 = (unsigned)chunk * 16u;
+        const bool upper = chunk >= 4;
+        int a_b[NA], a_oy[NA], a_ox[NA];
+        bool a_ok[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + i * LR + lrow;
+            a_ok[i] = m < p.M;
+            const int mm = a_ok[i] ? m : 0;
+            if (p.HW == 1) {
+                a_b[i] = mm;
+                a_oy[i] = a_ox[i] = 0;
+            } else {
+                a_b[i] = mm / p.HW;
+                const int rem = mm - a_b[i] * p.HW;
+                a_oy[i] = rem / p.OW;
+                a_ox[i] = rem - a_oy[i] * p.OW;
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
+        const GemmSrcK S = p.src[0];
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)S.ptr, 0, S.bytes, IDB_RSRC_FLAGS);
+        unsigned w_voff[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + j * LR + lrow;
+            w_voff[j] = (n < p.N && j * LR + lrow < BN) ? (unsigned)n * p.w_row_bytes + cg16 : IDB_OOB;
+        }
+        unsigned w_soff = 0;
+        int tap = S.taps == 9 ? 0 : 4, c0 = 0;
+        unsigned a_voff[NA];
+        bool need_retap = true;
+        auto stage = [&](int buf) __attribute__((always_inline)) {
+            char* sA = smem + buf * STAGE;
+            char* sB = sA + BM * 128;
+            if (need_retap) {
+                const int t3 = tap / 3;
+                const int dy = t3 - p.pad, dx = tap - t3 * 3 - p.pad;
+                const int LH = S.H << S.up, LWd = S.W << S.up;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
+                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LWd;
+                    const int pix = (a_b[i] * S.H + (iy >> S.up)) * S.W + (ix >> S.up);
+                    a_voff[i] = ok ? (unsigned)pix * (unsigned)S.C + cg16 : IDB_OOB;
+                }
+                need_retap = false;
+            }
+            const bool tail = c0 + 128 > S.C;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(sA + (i * 64 * LW + lw * 64) * 16), 16, (tail && upper) ? IDB_OOB : a_voff[i],
+                                                         (unsigned)c0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * 64 * LW + lw * 64) * 16), 16, w_voff[j], w_soff, 0, 0);
+            w_soff += 128u;
+            c0 += 128;
+            if (c0 >= S.C) {
+                c0 = 0;
+                need_retap = true;
+                ++tap;
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st)
+            if (st < nk) stage(st);
+        int cur = 0;
+        for (int it = 0; it < nk; ++it) {
+            if (it + NS - 2 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * LOADS) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (it + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1);
+            cur = cur + 1 == NS ? 0 : cur + 1;
+        }
+        return;                                            // s_barrier counts the surviving waves only
+    }
+
+    // ---------------- MFMA waves ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
+        const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
+        const int p0 = ((2 * fg) ^ (fr & 7)) * 16, p1 = ((2 * fg + 1) ^ (fr & 7)) * 16;
+        i32x8 wf[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const i32x4 lo = *(const i32x4*)(sB + j * 16 * 128 + p0), hi = *(const i32x4*)(sB + j * 16 * 128 + p1);
+            wf[j] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const i32x4 lo = *(const i32x4*)(sA + i * 16 * 128 + p0), hi = *(const i32x4*)(sA + i * 16 * 128 + p1);
+            const i32x8 af = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        }
+        cur = cur + 1 == NS ? 0 : cur + 1;
+    }
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int n = n0 + (wn * NF + j) * 16 + fg * 4;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        if (n + 3 < p.N) sc = *(const f32x4*)(p8.w_scale + n);
+        else
+            for (int e = 0; e < 4; ++e) sc[e] = n + e < p.N ? p8.w_scale[n + e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] *= sc[e] * p8.x_scale;
+    }
+    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, 0);
+#endif
+}
+
 // x (operand dtype) -> fp8 e4m3 of x * inv_scale, saturating at +-448; 8 elements per thread
 template <typename T>
 __global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* x, unsigned char* out, long long count, float inv_scale) {
@@ -233,6 +385,25 @@ int launch_gemm8(const Gemm8Params& p, int tiles, hipStream_t st) {
     }
     hipLaunchKernelGGL((idb_gemm8_kernel<T, MF, NF, NS>), dim3(tiles), dim3(512), LDS, st, p);
     IDB_CHECK_LAUNCH("idb_gemm_fp8");
+    return IDB_OK;
+}
+
+template <typename T, int MF, int NF, int NS, int LW>
+int launch_gemm8_lw(const Gemm8Params& p, int tiles, hipStream_t st) {
+    constexpr int LR = 8 * LW, NJ = (32 * NF + LR - 1) / LR;
+    constexpr int LDS = (16 * MF * 4 + NJ * LR) * 128 * NS;
+    static_assert(LDS <= 160 * 1024, "LDS ring does not fit");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_gemm8_kernel_lw<T, MF, NF, NS, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            idb_set_error("idb_gemm_fp8: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
+            return IDB_EHIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((idb_gemm8_kernel_lw<T, MF, NF, NS, LW>), dim3(tiles), dim3(512 + 64 * LW), LDS, st, p);
+    IDB_CHECK_LAUNCH("idb_gemm_fp8(lw)");
     return IDB_OK;
 }
 
@@ -305,13 +476,18 @@ extern "C" int idb_gemm_fp8(const idb_gemm_fp8_desc* d, void* stream) {
     p.cpad = cpad;
     const int nf = d->n % 160 == 0 ? 5 : 4;
     g.tiles_n = (d->n + 32 * nf - 1) / (32 * nf);
-    const int tiles = (int)((M + 127) / 128) * g.tiles_n;
+    // large grids with K >= 1280: 256-row loader-wave tiles (one workgroup per CU, 8 MFMA + 4 loader waves); IDB_GEMM8_BIG_TILES=0: off
+    const char* env_big_s = getenv("IDB_GEMM8_BIG_TILES");          // read per call: tests compare both tile forms in one process
+    const int env_big = env_big_s ? atoi(env_big_s) : 512;
+    const bool big = env_big > 0 && g.ktiles >= 10 && ((M + 255) / 256) * g.tiles_n >= env_big;
+    const int bm = big ? 256 : 128;
+    const int tiles = (int)((M + bm - 1) / bm) * g.tiles_n;
     hipStream_t st = (hipStream_t)stream;
     bool gn_after = false;                 // first GroupNorm pass of the output: from the shared LDS-staged epilogue when it can
     if (d->gn_partials) {
         IDB_REQUIRE(d->gn_groups > 0 && d->n % d->gn_groups == 0 && g.HW % 64 == 0 && g.HW <= 4096 && d->out_ld == d->n && idb_aligned16(d->gn_partials),
                     "idb_gemm_fp8: gn_partials needs n %% gn_groups == 0, out_h*out_w %% 64 == 0 and <= 4096, dense output");
-        if (idb_epilogue_emits_gn(128, 32 * nf, 512, M, d->n, d->gn_groups)) {
+        if (idb_epilogue_emits_gn(bm, 32 * nf, 512, M, d->n, d->gn_groups)) {
             g.gn_part = d->gn_partials;
             g.gn_groups = d->gn_groups;
         } else {
@@ -319,7 +495,10 @@ extern "C" int idb_gemm_fp8(const idb_gemm_fp8_desc* d, void* stream) {
         }
     }
     int rc;
-    if (d->out_dtype == IDB_BF16) rc = nf == 5 ? launch_gemm8<__bf16, 2, 5, 2>(p, tiles, st) : launch_gemm8<__bf16, 2, 4, 2>(p, tiles, st);
+    if (big) {
+        if (d->out_dtype == IDB_BF16) rc = nf == 5 ? launch_gemm8_lw<__bf16, 4, 5, 3, 4>(p, tiles, st) : launch_gemm8_lw<__bf16, 4, 4, 3, 4>(p, tiles, st);
+        else rc = nf == 5 ? launch_gemm8_lw<_Float16, 4, 5, 3, 4>(p, tiles, st) : launch_gemm8_lw<_Float16, 4, 4, 3, 4>(p, tiles, st);
+    } else if (d->out_dtype == IDB_BF16) rc = nf == 5 ? launch_gemm8<__bf16, 2, 5, 2>(p, tiles, st) : launch_gemm8<__bf16, 2, 4, 2>(p, tiles, st);
     else rc = nf == 5 ? launch_gemm8<_Float16, 2, 5, 2>(p, tiles, st) : launch_gemm8<_Float16, 2, 4, 2>(p, tiles, st);
     if (rc != IDB_OK || !gn_after) return rc;
     return idb_launch_gn_stats64(d->out, d->n, d->batch, g.HW, d->gn_groups, d->gn_partials, d->out_dtype, st);

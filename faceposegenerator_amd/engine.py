@@ -120,23 +120,15 @@ class HipEngine:
         self._gn_sync = torch.zeros(1 << 14, dtype=torch.int32, device=self.device) if os.environ.get("IDB_GN_SYNC") == "1" else None
         # first GroupNorm pass produced by the GEMM that writes the tensor (idb_gemm_desc.gn_partials); IDB_GN_FUSE=0 disables
         self._gn_fuse = os.environ.get("IDB_GN_FUSE", "1") != "0"
-        # GroupNorm(+SiLU) applied inside the consuming conv (idb_hconv).  Measured on MI355X at batch 1 (tools/bench_hconv.py,
-        # DESIGN.md section 5): 47 us against 31 + 9.6 us for idb_gemm + the gn_apply launch on the 320->320 @64x64 layer, 5.70
-        # against 6.62 images/s end to end — the in-LDS SiLU costs more than the launch it saves, so the policy default is OFF and
-        # IDB_HCONV=1 turns it on (grids of at most IDB_HCONV_TILES 128-row tiles: the kernel holds one workgroup per CU).
         # LayerNorm folded into the consuming projection (to_q/k/v, attn2.to_q, GEGLU-in): row statistics from the producer's epilogue,
         # rstd / mean correction in the consumer's; IDB_LN_FOLD=0 keeps the idb_layernorm launches
         self._ln_fold = os.environ.get("IDB_LN_FOLD", "1") != "0"
         self._fold_cache: Dict[Tuple[int, int, int, bool], bool] = {}
         self._ff_chunk_bytes = int(os.environ.get("IDB_FF_CHUNK_MB", "160")) << 20       # 0: the feed-forward in one piece
         self._gn_epi = os.environ.get("IDB_GN_EPILOGUE", "1") != "0"      # GroupNorm statistics from non-split GEMM epilogues
-        self._use_hconv = os.environ.get("IDB_HCONV", "0") == "1"
-        self._hconv_tiles = int(os.environ.get("IDB_HCONV_TILES", "512"))
-        self._hconv_proj_in = os.environ.get("IDB_HCONV_PROJ_IN", "1") != "0"      # Transformer2DModel.norm + proj_in fused as well
-        self._hconv_resnet = os.environ.get("IDB_HCONV_RESNET", "1") != "0"        # ResnetBlock2D norm1+conv1 / norm2+conv2
         # weights in the K-tiled 16-row-block layout (idb_tile_weight): a workgroup's K loop reads each of its row blocks as one
         # contiguous stream instead of 128-byte pieces at a K*2-byte stride; IDB_W_TILED=0 keeps [n][K] rows
-        self._w_tiled = os.environ.get("IDB_W_TILED", "1") != "0" and not self._use_hconv
+        self._w_tiled = os.environ.get("IDB_W_TILED", "1") != "0"
         self.x8_scale: Dict[str, float] = {}           # fp8 path: e4m3 scale of each GroupNorm+SiLU output (fp8_act_scale)
         self.w: Dict[str, torch.Tensor] = {}
         self.w_rows: Dict[str, torch.Tensor] = {}      # [n][K] row form of the LoRA-affected matrices (set_lora writes here, then re-tiles)
@@ -611,65 +603,6 @@ class HipEngine:
                                              C.byref(chunks), self.dt, _stream()), "idb_groupnorm_stats")
         return part, chunks.value
 
-    def _hconv_desc(self, segs, w, n, batch, h, w_, gn, bias, sbias, residual, gn_stats, out) -> "L.HconvDesc":
-        d = L.HconvDesc()
-        d.dtype, d.batch, d.h, d.w, d.n, d.nseg = self.dt, batch, h, w_, n, len(segs)
-        for i, (x0, c0, x1, c1, taps) in enumerate(segs):
-            d.seg[i].x0, d.seg[i].c0, d.seg[i].x1, d.seg[i].c1, d.seg[i].taps = x0.data_ptr(), c0, _ptr(x1), c1, taps
-        if gn is not None:
-            part, chunks, groups, eps, gamma, beta, silu = gn
-            d.gn_partials = part if isinstance(part, int) else part.data_ptr()
-            d.gn_chunks, d.gn_groups, d.gn_eps, d.silu = chunks, groups, eps, int(silu)
-            d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
-        d.w_ptr, d.bias = w.data_ptr(), _ptr(bias)
-        if sbias is not None:
-            d.sample_bias = sbias[0].data_ptr() + 4 * sbias[1]
-            d.sample_bias_ld = sbias[2]
-        d.residual = _ptr(residual)
-        d.out = out if isinstance(out, int) else out.data_ptr()
-        d.out_ld = n
-        if gn_stats:
-            d.gn_groups_out = gn_stats
-        return d
-
-    def hconv_supported(self, segs, w, n, batch, h, w_, gn_groups: int = 0) -> bool:
-        """Would idb_hconv take this shape (and is the grid in the kernel's one-workgroup-per-CU regime)?  Host-only."""
-        if (batch * h * w_) % 128 or (batch * h * w_ // 128) * ((n + 159) // 160) > self._hconv_tiles:
-            return False
-        dummy = self._gn_ws.data_ptr()
-        gn = (dummy, 1, gn_groups, 1e-5, self._gn_ws, self._gn_ws, True) if gn_groups else None
-        d = self._hconv_desc(segs, w, n, batch, h, w_, gn, None, None, None, 0, dummy)
-        return self.lib.idb_hconv_plan(C.byref(d), None, None) == 0
-
-    def hconv(self, segs, w, n, batch, h, w_, gn=None, bias=None, sbias=None, residual=None, gn_stats: int = 0,
-              split_k: int = 0) -> torch.Tensor:
-        """GroupNorm(+SiLU) -> conv3x3 / 1x1 in one kernel (idb_hconv).  segs: [(x0, c0, x1, c1, taps)], the first one normalised
-        with gn = (partials, chunks, groups, eps, gamma, beta, silu); gn_stats: emit the output's statistics for the next norm."""
-        hw = h * w_
-        out = self.arena.alloc((batch * hw, n), self.tdt)
-        d = self._hconv_desc(segs, w, n, batch, h, w_, gn, bias, sbias, residual, 0, out)
-        d.split_k = split_k
-        gn_part = None
-        if gn_stats and hw % 64 == 0 and hw <= 4096 and n % gn_stats == 0 and n // gn_stats >= 2:
-            gn_part = self.arena.alloc((batch * (hw // 64) * gn_stats * 2,), torch.float32)
-            d.gn_partials_out, d.gn_groups_out = gn_part.data_ptr(), gn_stats
-        need = self.lib.idb_hconv_workspace_bytes(C.byref(d))
-        ws = self._workspace(need) if need else None
-        log = self.launch_log
-        if log is not None:
-            sk, blocks = C.c_int32(), C.c_int32()
-            L.check(self.lib.idb_hconv_plan(C.byref(d), C.byref(sk), C.byref(blocks)), "idb_hconv_plan")
-            k_total = sum((c0 + c1) * taps for (_, c0, _, c1, taps) in segs)
-        L.check(self.lib.idb_hconv(C.byref(d), _ptr(ws), need, _stream()), "idb_hconv")
-        if gn_part is not None:
-            out._gn = (gn_part, hw // 64, gn_stats)
-        if log is not None:
-            m = batch * hw
-            log.append({"tile": 100 + (5 if n % 160 == 0 else 4), "split_k": sk.value, "blocks": blocks.value, "m": m, "n": n, "k": k_total,
-                        "flops": 2.0 * m * n * k_total, "desc": d, "ws": (ws, need), "hconv": True,
-                        "bytes": 2.0 * (sum(m * (c0 + c1) for (_, c0, _, c1, _) in segs) + n * k_total + m * n)})
-        return out
-
     # ---- fp8 (e4m3) GEMM path: kernel level of BASELINE configs[4] (idb_gemm8.hip) -------------------------------------------
     def quantize_fp8(self, x: torch.Tensor, scale: float) -> torch.Tensor:
         """operand-dtype tensor -> uint8 storage of e4m3(x / scale) (saturating)."""
@@ -781,24 +714,6 @@ class HipEngine:
         cin = ca + cb
         G0 = groups or self.ucfg.norm_num_groups
         short = f"{name}.has_shortcut" in W
-        seg1 = [(xa, ca, xb, cb, 9)]
-        if self._use_hconv and self._hconv_resnet and self.hconv_supported(seg1, W[f"{name}.conv1.w"], cout, batch, h, w_, G0) and \
-                self.hconv_supported([(xa, cout, None, 0, 9)] + ([(xa, ca, xb, cb, 1)] if short else []), W[f"{name}.conv2.w"], cout,
-                                     batch, h, w_, G0):
-            # GroupNorm+SiLU inside both convs (idb_hconv): norm1+conv1(+temb), norm2+conv2(+1x1 shortcut | +residual)
-            sb = None if sbias is None else (sbias[0], sbias[1] + self.tproj_off[name], sbias[2])
-            part, chunks = self.gn_statistics(xa, ca, xb, cb, batch, h * w_, G0)
-            h1 = self.hconv(seg1, W[f"{name}.conv1.w"], cout, batch, h, w_, gn=(part, chunks, G0, eps, W[f"{name}.gn1.g"],
-                            W[f"{name}.gn1.b"], True), bias=W[f"{name}.conv1.b"], sbias=sb, gn_stats=G0)
-            self.arena.free(part)
-            part, chunks = self.gn_statistics(h1, cout, None, 0, batch, h * w_, G0)
-            seg2 = [(h1, cout, None, 0, 9)] + ([(xa, ca, xb, cb, 1)] if short else [])
-            out = self.hconv(seg2, W[f"{name}.conv2.w"], cout, batch, h, w_, gn=(part, chunks, G0, eps, W[f"{name}.gn2.g"],
-                             W[f"{name}.gn2.b"], True), bias=W[f"{name}.conv2.b"], residual=None if short else xa,
-                             gn_stats=G0 if out_stats else 0)
-            self.arena.free(part)
-            self.arena.free(h1)
-            return out
         if self.fp8 and f"{name}.conv1.w8" in W:
             # fp8 MFMA path: GroupNorm+SiLU -> e4m3, conv on v_mfma_scale_f32_16x16x128_f8f6f4; the 1x1 shortcut over the raw inputs
             # stays an f16 GEMM whose result enters the second conv as its residual
@@ -846,15 +761,9 @@ class HipEngine:
         hw = h * w_
         m = batch * hw
         G = self.ucfg.norm_num_groups
-        if self._use_hconv and self._hconv_proj_in and self.hconv_supported([(x, c, None, 0, 1)], W[f"{n}.proj_in.w"], c, batch, h, w_, G):
-            part, chunks = self.gn_statistics(x, c, None, 0, batch, hw, G)
-            h0 = self.hconv([(x, c, None, 0, 1)], W[f"{n}.proj_in.w"], c, batch, h, w_, gn=(part, chunks, G, 1e-6, W[f"{n}.norm.g"],
-                            W[f"{n}.norm.b"], False), bias=W[f"{n}.proj_in.b"])
-            self.arena.free(part)
-        else:
-            xn = self.groupnorm(x, c, None, 0, batch, hw, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
-            h0 = self.linear(xn, W[f"{n}.proj_in.w"], c, c, bias=W[f"{n}.proj_in.b"], row_stats=self.folds(xn, m, c, 3 * c))
-            self.arena.free(xn)
+        xn = self.groupnorm(x, c, None, 0, batch, hw, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
+        h0 = self.linear(xn, W[f"{n}.proj_in.w"], c, c, bias=W[f"{n}.proj_in.b"], row_stats=self.folds(xn, m, c, 3 * c))
+        self.arena.free(xn)
         # self-attention
         qkv = self.ln_linear(h0, m, c, n, "ln1", "qkv", 3 * c)
         self._free_rs(h0)

@@ -190,56 +190,10 @@ int idb_groupnorm(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_
 int idb_layernorm(const void* x, void* out, int64_t rows, int32_t c, float eps, const float* gamma,
                   const float* beta, int32_t dtype, void* stream);
 /* First GroupNorm pass only: partial {sum, sum of squares} per (sample, pixel chunk, group) of the channel concatenation x0 | x1,
- * fp32 [batch][*chunks][groups][2] in `partials` (capacity: idb_groupnorm_workspace_bytes) — the statistics input of idb_hconv
- * for tensors whose producer did not emit them (skip concatenations, conv_in).  *chunks receives the pixel-chunk count (<= 64). */
+ * fp32 [batch][*chunks][groups][2] in `partials` (capacity: idb_groupnorm_workspace_bytes) — for callers that
+ * want the statistics of a tensor whose producer did not emit them (skip concatenations, conv_in).  *chunks receives the pixel-chunk count (<= 64). */
 int idb_groupnorm_stats(const void* x0, int32_t c0, const void* x1, int32_t c1, int32_t batch, int32_t hw, int32_t groups,
                         float* partials, size_t partials_bytes, int32_t* chunks, int32_t dtype, void* stream);
-
-/* ------------------------------------------------------------------------------------------
- * K1 fused — GroupNorm(32, C, eps) [+ SiLU] -> Conv2d 3x3 (stride 1, padding 1) / 1x1, i.e. diffusers ResnetBlock2D
- * norm1+conv1 and norm2+conv2(+conv_shortcut, + residual) and Transformer2DModel norm+proj_in, in ONE kernel: the normalised
- * tensor is never written to HBM (north_star "conv3x3 + GroupNorm+SiLU fused"; UNet2DConditionModel.forward via
- * inference_ID-Booth.py:138).  out[m][n] = sum over segments, taps, channels of f(x)[pixel(m) + tap][c] * W[n][k] (+ epilogue).
- * Up to two K segments, each the channel concatenation x0 | x1 of NHWC tensors [batch][h][w][c] with taps = 9 or 1; W rows are
- * [segment 0: tap-major [tap][c0 + c1]] [segment 1: ...] as idb_pack_conv_weight / idb_pack_matrix lay them out.  Segment 0 may
- * carry the fused GroupNorm: gn_partials = its statistics ([batch][gn_chunks][gn_groups][2], from idb_gemm_desc.gn_partials,
- * idb_hconv_desc.gn_partials_out or idb_groupnorm_stats), gamma / beta [c0 + c1]; padding pixels stay zero AFTER the activation.
- * Shapes: batch*h*w % 128 == 0 and (w <= 64, 128 % w == 0, h*w % 128 == 0) or (h*w < 128, 128 % (h*w) == 0); other shapes and
- * K slices whose normalised channel range does not fit the in-LDS table return IDB_EUNSUPPORTED (idb_hconv_plan tells
- * beforehand): the caller then uses idb_groupnorm + idb_gemm.  Epilogue, split-K and gn_partials_out as idb_gemm.
- * ------------------------------------------------------------------------------------------ */
-typedef struct {
-    const void* x0; int32_t c0;
-    const void* x1; int32_t c1;   /* NULL / 0: no concatenation */
-    int32_t taps;                 /* 9 or 1 */
-} idb_hconv_seg;
-
-typedef struct {
-    int32_t dtype, batch, h, w, n;
-    int32_t nseg;
-    idb_hconv_seg seg[2];
-    const float* gn_partials;     /* NULL: segment 0 is used as it is */
-    int32_t gn_chunks, gn_groups;
-    float gn_eps;
-    const float* gamma;
-    const float* beta;
-    int32_t silu;
-    const void* w_ptr;            /* [n][K] operand dtype */
-    const float* bias;
-    const float* sample_bias;
-    int32_t sample_bias_ld;
-    const void* residual;         /* [M][out_ld] operand dtype or NULL */
-    void* out;                    /* operand dtype */
-    int32_t out_ld;
-    int32_t split_k;              /* 0 = heuristic */
-    float* gn_partials_out;       /* optional: statistics of the output for the next GroupNorm, as idb_gemm_desc.gn_partials */
-    int32_t gn_groups_out;
-    int32_t flags;                /* measurements only — bit 0: skip the split-K reduce / statistics launches (`out` not written) */
-} idb_hconv_desc;
-
-size_t idb_hconv_workspace_bytes(const idb_hconv_desc* d);
-int idb_hconv_plan(const idb_hconv_desc* d, int32_t* split_k, int32_t* blocks);
-int idb_hconv(const idb_hconv_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4/K5 — fused attention, head_dim 64: out = softmax(Q K^T * scale) V, online softmax in fp32.

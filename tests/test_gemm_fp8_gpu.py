@@ -95,3 +95,30 @@ def test_gemm_fp8_emits_groupnorm_partials(eng, b, side, cin, cout):
     part = st[0].view(b, hw // 64, 32, 2).double()
     assert torch.allclose(part[..., 0], yr.sum(dim=(2, 4)), rtol=1e-5, atol=1e-3)
     assert torch.allclose(part[..., 1], (yr * yr).sum(dim=(2, 4)), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("b,h,cin,cout,taps", [(64, 32, 320, 320, 9), (128, 16, 1280, 640, 9), (64, 32, 1280, 320, 1), (32, 48, 192, 320, 9)])
+def test_gemm_fp8_256_row_loader_wave_tiles_bit_identical(eng, b, h, cin, cout, taps):
+    """Large grids with K >= 1280 run the 256-row loader-wave form (idb_gemm8_kernel_lw: 8 MFMA + 4 DMA-only waves, one workgroup
+    per CU); IDB_GEMM8_BIG_TILES=0 forces the 128-row kernel: same fragment mapping and accumulation order, so bit-identical —
+    residual, per-sample bias and the GroupNorm-statistics epilogue included."""
+    import os
+    x = _rand((b, h, h, cin), 20, 2.0).to(eng.tdt)
+    wt = _rand((cout, cin, 3, 3) if taps == 9 else (cout, cin, 1, 1), 21, (taps * cin) ** -0.5)
+    bias, sb = _rand((cout,), 22), _rand((b, cout), 23)
+    res = _rand((b * h * h, cout), 24).to(eng.tdt)
+    x_scale = 6.0 / 448.0
+    x8 = eng.quantize_fp8(x, x_scale)
+    w8, ws = eng.pack_weight_fp8(wt)
+    outs = []
+    for big in ("512", "0"):
+        os.environ["IDB_GEMM8_BIG_TILES"] = big
+        try:
+            o = eng.gemm_fp8(x8, x_scale, cin, taps, h, h, w8, ws, cout, b, h, h, bias=bias, sbias=(sb, 0, cout), residual=res, gn_stats=32)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("IDB_GEMM8_BIG_TILES", None)
+        outs.append((o.clone(), None if getattr(o, "_gn", None) is None else o._gn[0].clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if outs[0][1] is not None and outs[1][1] is not None:
+        assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-2)

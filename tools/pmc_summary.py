@@ -12,6 +12,17 @@ import sys
 
 
 def short(n):
+    m = re.search(r"idb_gemm_kernel_lwI(DF16b|DF16_)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E", n)
+    if m:                                       # loader-wave variants: the display names of bench.TILE_NAMES
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        mf, nf, ns, wm, lw = (int(m.group(i)) for i in range(2, 7))
+        for big in (False, True):
+            for shape, cfg in bench._KTILES.items():
+                if cfg == (mf // 2 if big else mf, nf, wm) and (not big or mf % 2 == 0) and shape in ((8, 9) if big else (4, 6, 7, 8, 9)):
+                    v = 8 if big else {(3, 4): 5, (3, 8): 6, (4, 4): 7}[(ns, lw)]
+                    return bench.TILE_NAMES[10 * v + shape]
     m = re.search(r"idb_gemm_kernel(_rs|_pl)?I(DF16b|DF16_)Li(\d)ELi(\d)E(?:Li(\d)E)?(?:Li(\d)E)?", n)
     if m:
         wm = int(m.group(6) or 2)
