@@ -46,7 +46,8 @@ class GemmDesc(C.Structure):
                 ("split_k", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float), ("flags", C.c_int32), ("act", C.c_int32),
                 ("counters", C.c_void_p), ("counters_len", C.c_int32), ("gn_partials", C.c_void_p), ("gn_groups", C.c_int32),
                 ("row_stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_tiles", C.c_int32), ("ln_u", C.c_void_p),
-                ("ln_v", C.c_void_p), ("ln_eps", C.c_float), ("pad_mode", C.c_int32), ("w_layout", C.c_int32)]
+                ("ln_v", C.c_void_p), ("ln_eps", C.c_float), ("pad_mode", C.c_int32), ("w_layout", C.c_int32),
+                ("w_groups", C.c_int32), ("w_group_rows", C.c_int32), ("w_group_stride", C.c_int64)]
 
 
 class GemmFp8Desc(C.Structure):

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(128 * WM, 2) void idb_gemm_kernel(const GemmParams 
         }
     }
     // weights: one descriptor, per-row voffset fixed for the whole K loop, K position in the SGPR soffset
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + idb_weight_group(p, m0) * p.w_group_stride), 0, p.w_bytes, IDB_RSRC_FLAGS);
     unsigned w_voff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(128 * WM + 64 * LW) void idb_gemm_kernel_lw(const G
                 a_ox[i] = rem - a_oy[i] * p.OW;
             }
         }
-        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + idb_weight_group(p, m0) * p.w_group_stride), 0, p.w_bytes, IDB_RSRC_FLAGS);
         unsigned w_voff[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void idb_gemm_kernel_rs(const GemmParams p)
             a_ox[i] = rem - a_oy[i] * p.OW;
         }
     }
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, IDB_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + idb_weight_group(p, m0) * p.w_group_stride), 0, p.w_bytes, IDB_RSRC_FLAGS);
     unsigned w_voff[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
@@ -1340,6 +1340,19 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     if (d->gn_partials && pl.splitk == 1 && !(d->flags & 1) && gemm_epilogue_emits_gn(d, pl, d->gn_groups)) {
         p.gn_part = d->gn_partials;          // launch_all's idb_finish_splitk then has nothing left to launch
         p.gn_groups = d->gn_groups;
+    }
+    p.w_groups = d->w_groups > 1 ? d->w_groups : 1;
+    p.w_group_rows = d->w_group_rows;
+    p.w_group_stride = d->w_group_stride;
+    if (p.w_groups > 1) {
+        const int bm_t = 16 * kTiles[pl.tile % 10].mf * kTiles[pl.tile % 10].wm * (pl.tile / 10 == 8 ? 2 : 1);
+        IDB_REQUIRE(d->w_group_rows > 0 && d->w_group_stride >= (long long)p.w_bytes && d->w_group_stride % 16 == 0 &&
+                        (long long)d->w_groups * d->w_group_stride < (1LL << 40), "idb_gemm: w_groups needs w_group_rows > 0 and a 16-byte-multiple w_group_stride >= one matrix");
+        if (pl.tile / 10 == 4 || d->w_group_rows % bm_t != 0) {
+            idb_set_error("idb_gemm: w_group_rows = %d is not a multiple of the plan's tile height %d (or the persistent variant was chosen): run one launch per group",
+                          d->w_group_rows, bm_t);
+            return IDB_EUNSUPPORTED;
+        }
     }
     p.rowstat_out = d->row_stats_out;
     p.ln_stats = d->ln_stats;

@@ -43,7 +43,13 @@ struct GemmParams {
     // the tile's column range holds whole groups (host: idb_epilogue_emits_gn)
     float* gn_part;
     int gn_groups;
+    // grouped weights (idb_gemm_desc.w_groups): tile rows [m0, m0 + BM) use matrix (m0 / w_group_rows) % w_groups
+    int w_groups, w_group_rows;
+    long long w_group_stride;
 };
+
+// byte offset of the weight matrix (and element offset of its folded-LayerNorm vectors) a tile uses
+__device__ __forceinline__ int idb_weight_group(const GemmParams& p, int m0) { return p.w_groups > 1 ? (m0 / p.w_group_rows) % p.w_groups : 0; }
 
 // voffset of a lane that must read zeros: beyond num_records of every descriptor (all < 2^31), and
 // voffset + soffset cannot wrap, whichever of the two the hardware range check looks at.
@@ -125,8 +131,9 @@ __device__ __forceinline__ void idb_load_colvecs(const GemmParams& p, int m0, in
     const int m_last = min(m0 + BM, p.M) - 1;
     const bool sb_tile = p.sbias && (m0 / p.HW == m_last / p.HW);
     const float* dummy = (const float*)p.w;
-    const float* pa = ln ? p.ln_v : p.bias;
-    const float* pb = ln ? p.ln_u : (sb_tile ? p.sbias + (long long)(m0 / p.HW) * p.sbias_ld : nullptr);
+    const long long go = (long long)idb_weight_group(p, m0) * p.N;           // grouped weights: one (u, v) pair per group
+    const float* pa = ln ? p.ln_v + go : p.bias;
+    const float* pb = ln ? p.ln_u + go : (sb_tile ? p.sbias + (long long)(m0 / p.HW) * p.sbias_ld : nullptr);
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const int nc = min(n0 + (wn * NF + j) * 16 + fg * 4, p.N - 4);

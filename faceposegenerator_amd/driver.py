@@ -206,34 +206,62 @@ def synthetic_embed_fn(cross_dim: int, n_ctx: int = 77) -> Callable[[Sequence[st
     return fn
 
 
+def plan_calls(items: Sequence[WorkItem], max_batch: int = 64, group_identities: int = 1) -> List[List[List[WorkItem]]]:
+    """The pipeline calls one rank makes for its `items`: a list of calls, each a list of per-identity item lists (one entry unless
+    identities are grouped).  Items of one (identity, model) pair keep the reference's generator stream order and are cut into
+    sub-batches of at most `max_batch`.  group_identities = G > 1: sub-batches of the SAME model and the same length from up to G
+    different identities share one call (one merged LoRA set per group of the batch, `load_lora_weights([...])`), as long as
+    G * length <= max_batch — BASELINE configs[2]'s 8 identities x 8 prompts become one batch-64 call."""
+    pairs: Dict[Tuple[int, str], List[WorkItem]] = {}
+    for it in items:
+        pairs.setdefault((it.id_number, it.model_name), []).append(it)
+    subs: List[List[WorkItem]] = []
+    for group_items in pairs.values():
+        for b0 in range(0, len(group_items), max_batch):
+            sub = group_items[b0:b0 + max_batch]
+            assert [it.stream_offset for it in sub] == list(range(sub[0].stream_offset, sub[0].stream_offset + len(sub)))
+            subs.append(sub)
+    if group_identities <= 1:
+        return [[sub] for sub in subs]
+    calls: List[List[List[WorkItem]]] = []
+    pending: Dict[Tuple[str, int, int], List[List[WorkItem]]] = {}        # (model, length, first stream offset) -> sub-batches waiting
+    for sub in subs:
+        key = (sub[0].model_name, len(sub), sub[0].stream_offset)
+        grp = pending.setdefault(key, [])
+        grp.append(sub)
+        if len(grp) == group_identities or (len(grp) + 1) * len(sub) > max_batch:
+            calls.append(pending.pop(key))
+    calls += [g for g in pending.values()]
+    return calls
+
+
 def generate(pipe, items: Sequence[WorkItem], embed_fn: Callable, cfg: PolicyConfig = PolicyConfig(),
              lora_for: Optional[Callable[[str, str], object]] = None, rank: int = 0, world: int = 1,
-             max_batch: int = 64, group=None) -> Tuple[torch.Tensor, List[WorkItem]]:
+             max_batch: int = 64, group=None, group_identities: int = 1) -> Tuple[torch.Tensor, List[WorkItem]]:
     """Run this rank's share of `items` and all-gather the uint8 images.  Items of one (identity, model) pair are
-    batched into single pipeline calls (B up to `max_batch`) with the reference's generator stream order.
-    `lora_for(model_name, which_id)` returns what ``load_lora_weights`` accepts (path or state dict).
-    Returns (images [len(items), H, W, 3] uint8 in rank-major work order, the items in that order)."""
+    batched into single pipeline calls (B up to `max_batch`) with the reference's generator stream order; with
+    group_identities = G > 1 (and `lora_for`) up to G identities of the same model share one call, each group of the batch with
+    its own merged LoRA set (``plan_calls``).  `lora_for(model_name, which_id)` returns what ``load_lora_weights`` accepts (path
+    or state dict).  Returns (images [len(items), H, W, 3] uint8 in rank-major work order, the items in that order)."""
     mine = shard_work(items, rank, world)
     order: List[WorkItem] = []
     chunks: List[torch.Tensor] = []
     neg = NEGATIVE_PROMPT if not cfg.do_not_use_negative_prompt else ""
-    pairs: Dict[Tuple[int, str], List[WorkItem]] = {}
-    for it in mine:
-        pairs.setdefault((it.id_number, it.model_name), []).append(it)
     lat_shape = (pipe.unet_config.in_channels, cfg.height // pipe.vae_scale_factor, cfg.width // pipe.vae_scale_factor)
-    for (id_number, model_name), group_items in pairs.items():
+    G = group_identities if lora_for is not None else 1
+    for call in plan_calls(mine, max_batch, G):
         if lora_for is not None:
-            pipe.load_lora_weights(lora_for(model_name, group_items[0].which_id))
-        for b0 in range(0, len(group_items), max_batch):
-            sub = group_items[b0:b0 + max_batch]
-            assert [it.stream_offset for it in sub] == list(range(sub[0].stream_offset, sub[0].stream_offset + len(sub)))
-            noise = draw_noise_sequential(id_number, len(sub), cfg.num_inference_steps, lat_shape, sub[0].stream_offset)
-            pe = embed_fn([it.prompt for it in sub])
-            ne = embed_fn([neg] * len(sub))
-            out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=cfg.num_inference_steps,
-                       guidance_scale=cfg.guidance_scale, height=cfg.height, width=cfg.width, output_type="uint8", noise=noise)
-            chunks.append(out.images)
-            order += sub
+            sets = [lora_for(sub[0].model_name, sub[0].which_id) for sub in call]
+            pipe.load_lora_weights(sets if len(sets) > 1 else sets[0])
+        noise = torch.cat([draw_noise_sequential(sub[0].id_number, len(sub), cfg.num_inference_steps, lat_shape, sub[0].stream_offset)
+                           for sub in call], dim=1)
+        flat = [it for sub in call for it in sub]
+        pe = embed_fn([it.prompt for it in flat])
+        ne = embed_fn([neg] * len(flat))
+        out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=cfg.num_inference_steps,
+                   guidance_scale=cfg.guidance_scale, height=cfg.height, width=cfg.width, output_type="uint8", noise=noise)
+        chunks.append(out.images)
+        order += flat
     if chunks:
         local = torch.cat(chunks)
     else:
@@ -245,12 +273,7 @@ def generate(pipe, items: Sequence[WorkItem], embed_fn: Callable, cfg: PolicyCon
         if r == rank:
             all_order += order
         else:
-            theirs = shard_work(items, r, world)
-            tp: Dict[Tuple[int, str], List[WorkItem]] = {}
-            for it in theirs:
-                tp.setdefault((it.id_number, it.model_name), []).append(it)
-            for v in tp.values():
-                all_order += v
+            all_order += [it for call in plan_calls(shard_work(items, r, world), max_batch, G) for sub in call for it in sub]
     return images, all_order
 
 

@@ -129,6 +129,9 @@ class HipEngine:
         # weights in the K-tiled 16-row-block layout (idb_tile_weight): a workgroup's K loop reads each of its row blocks as one
         # contiguous stream instead of 128-byte pieces at a K*2-byte stride; IDB_W_TILED=0 keeps [n][K] rows
         self._w_tiled = os.environ.get("IDB_W_TILED", "1") != "0"
+        self.groups = 1                                # > 1: set_lora_groups is active (one merged LoRA set per group of samples)
+        self.wg: Dict[str, torch.Tensor] = {}          # grouped copies [G][...] of the LoRA-affected operands (tiled matrices, u / v)
+        self._rep = 1
         self.x8_scale: Dict[str, float] = {}           # fp8 path: e4m3 scale of each GroupNorm+SiLU output (fp8_act_scale)
         self.w: Dict[str, torch.Tensor] = {}
         self.w_rows: Dict[str, torch.Tensor] = {}      # [n][K] row form of the LoRA-affected matrices (set_lora writes here, then re-tiles)
@@ -386,6 +389,45 @@ class HipEngine:
                 raise ValueError(f"LoRA file has {n_pairs} adapter pairs but {used} matched UNet attention projections")
         self.lora_loaded = lora is not None      # stream-ordered: the next launch on this stream sees the merged weights
 
+    def set_lora_groups(self, loras: Sequence[Optional[SD]], scale: float = 1.0, alphas: Optional[Dict[str, float]] = None) -> None:
+        """A mixed-identity batch in ONE call (BASELINE configs[2]: 8 identities x 8 prompts): group g of the batch — samples
+        [g*B/G, (g+1)*B/G) — uses the merged weights of ``loras[g]``.  Each group's 128 matrices (and folded-LayerNorm vectors) are
+        built by ``set_lora`` and copied into slot g of grouped buffers; the GEMMs then select the matrix per row tile
+        (idb_gemm_desc.w_groups): the arithmetic is exactly the merged form of every identity, no epilogue work, no extra pass over x."""
+        G = len(loras)
+        if G <= 1:
+            self.groups = 1
+            self.set_lora(loras[0] if G else None, scale, alphas)
+            return
+        vec_keys = [k for a in self._attn_specs for k in (f"{a.name}.qkv.u", f"{a.name}.qkv.v", f"{a.name}.q2.u", f"{a.name}.q2.v")]
+        if not hasattr(self, "_wg_by_G"):
+            self._wg_by_G = {}                           # one buffer set per group count: captured graphs keep reading theirs
+        if G in self._wg_by_G:
+            self.wg = self._wg_by_G[G]
+        else:
+            self.wg = self._wg_by_G[G] = {}
+            for key in self.w_rows:
+                t = torch.empty((G, self.w[key].numel()), dtype=self.tdt, device=self.device)
+                t._groups, t._gshape = G, tuple(self.w_rows[key].shape)
+                if self._w_tiled:
+                    t._tiled = t._gshape
+                self.wg[key] = t
+            for key in vec_keys:
+                t = torch.empty((G, self.w[key].numel()), dtype=torch.float32, device=self.device)
+                t._groups = G
+                self.wg[key] = t
+        for g, lora in enumerate(loras):
+            self.set_lora(lora, scale, alphas)           # stream-ordered: fills self.w[...] / u / v for this identity
+            for key in self.w_rows:
+                self.wg[key][g].copy_(self.w[key].reshape(-1))
+            for key in vec_keys:
+                self.wg[key][g].copy_(self.w[key])
+        self.groups = G
+
+    def _Wl(self, key: str) -> torch.Tensor:
+        """LoRA-affected operand `key`: the grouped buffer while set_lora_groups is active, else the single merged one."""
+        return self.wg[key] if self.groups > 1 else self.w[key]
+
     def _pack_vae(self, sd: SD) -> None:
         w, g = self.w, self.vgraph
         w["v.pq.w"] = self._f32(sd["post_quant_conv.weight"].reshape(self.vcfg.latent_channels, -1))
@@ -482,6 +524,12 @@ class HipEngine:
         d.split_k, d.tile, d.out_scale, d.flags, d.act = split_k, tile, out_scale, flags, act
         d.pad_mode = pad_mode
         d.w_layout = 1 if getattr(w, "_tiled", None) is not None else 0
+        G = getattr(w, "_groups", 0) or 0
+        if G > 1:                                      # grouped weights: rows [r*M/rep + g*rpg, ... + rpg) of every CFG half r use matrix g
+            rep = self._rep
+            if m % (rep * G):
+                raise ValueError(f"grouped weights: {m} rows do not divide into {rep} x {G} groups")
+            d.w_groups, d.w_group_rows, d.w_group_stride = G, m // (rep * G), w.shape[1] * 2
         rs_buf = None
         if row_stats and self._ln_fold:
             nt = self.lib.idb_gemm_row_stats_tiles(C.byref(d))
@@ -517,7 +565,13 @@ class HipEngine:
             k_total = sum(ch * taps for (_, ch, taps, _, _, _) in srcs)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        L.check(self.lib.idb_gemm(C.byref(d), _ptr(ws), need, _stream()), "idb_gemm")
+        rc = self.lib.idb_gemm(C.byref(d), _ptr(ws), need, _stream())
+        if rc == -2 and G > 1:
+            # the plan's tile height does not divide the group's rows (cross-attention K/V of 77 tokens, tiny grids): one launch per
+            # (CFG half, group) on row slices — the same arithmetic
+            self._gemm_per_group(d, G, m // (self._rep * G), w, ws, need, ln)
+        else:
+            L.check(rc, "idb_gemm")
         if gn_part is not None:
             out._gn = (gn_part, oh * ow // 64, gn_stats)
         if rs_buf is not None:
@@ -528,6 +582,28 @@ class HipEngine:
                         "flops": 2.0 * m * n * k_total, "ev": (ev0, ev1), "desc": d, "ws": (ws, need),
                         "bytes": 2.0 * (m * k_total / (9 if srcs[0][2] == 9 else 1) + n * k_total + m * ncols)})
         return out
+
+    def _gemm_per_group(self, d, G: int, rpg: int, w: torch.Tensor, ws, need: int, ln) -> None:
+        """Fallback of the grouped-weights GEMM for plain [M][K] sources: row slice [j*rpg, (j+1)*rpg) with matrix j % G."""
+        if d.nsrc != 1 or d.src[0].taps != 1 or d.src[0].in_h != 1 or d.gn_partials or d.row_stats_out:
+            raise L.IdbError("grouped weights: per-group fallback needs one plain [M][K] source without statistics outputs")
+        m, k, esz = d.batch, d.src[0].channels, 2
+        osz = 4 if d.out_dtype == L.IDB_F32 else 2
+        base = {"a": d.src[0].ptr, "out": d.out, "res": d.residual, "w": d.w, "u": d.ln_u, "v": d.ln_v, "st": d.ln_stats}
+        for j in range(m // rpg):
+            g = j % G
+            d.batch = rpg
+            d.src[0].ptr = base["a"] + j * rpg * k * esz
+            d.out = base["out"] + j * rpg * d.out_ld * osz
+            d.residual = None if not base["res"] else base["res"] + j * rpg * d.out_ld * esz
+            d.w = base["w"] + g * d.w_group_stride
+            if ln is not None:
+                d.ln_u, d.ln_v = base["u"] + g * d.n * 4, base["v"] + g * d.n * 4
+                d.ln_stats = base["st"] + j * rpg * d.ln_tiles * 8
+            d.w_groups = 0
+            need_j = self.lib.idb_gemm_workspace_bytes(C.byref(d))
+            wsj = self._workspace(need_j) if need_j else None
+            L.check(self.lib.idb_gemm(C.byref(d), _ptr(wsj), need_j, _stream()), "idb_gemm (per group)")
 
     def linear(self, x: torch.Tensor, w: torch.Tensor, n: int, k: int, **kw) -> torch.Tensor:
         m = x.numel() // k
@@ -660,11 +736,12 @@ class HipEngine:
         rs = getattr(x, "_rs", None)
         if rs is not None and self._ln_fold:
             kf = {k: v for k, v in kw.items() if k != "bias"}          # the bias is part of .v
-            out = self.linear(x, W[f"{pfx}.{wname}.wln"], n, c, ln=(rs[0], rs[1], W[f"{pfx}.{wname}.u"], W[f"{pfx}.{wname}.v"], 1e-5), **kf)
+            lw = self._Wl if wname in ("qkv", "q2") else W.__getitem__
+            out = self.linear(x, lw(f"{pfx}.{wname}.wln"), n, c, ln=(rs[0], rs[1], lw(f"{pfx}.{wname}.u"), lw(f"{pfx}.{wname}.v"), 1e-5), **kf)
             if out is not None:
                 return out
         t = self.layernorm(x, rows, c, W[f"{pfx}.{ln_name}.g"], W[f"{pfx}.{ln_name}.b"])
-        out = self.linear(t, W[f"{pfx}.{wname}.w"], n, c, **kw)
+        out = self.linear(t, (self._Wl if wname in ("qkv", "q2") else W.__getitem__)(f"{pfx}.{wname}.w"), n, c, **kw)
         self.arena.free(t)
         return out
 
@@ -770,7 +847,7 @@ class HipEngine:
         p = qkv.data_ptr()
         o = self.attention(qkv, 3 * c, p + 2 * c, p + 4 * c, 3 * c, batch, a.heads, hw, hw, hw)
         self.arena.free(qkv)
-        h1 = self.linear(o, W[f"{n}.o1.w"], c, c, bias=W[f"{n}.o1.b"], residual=h0, row_stats=self.folds(o, m, c, c))
+        h1 = self.linear(o, self._Wl(f"{n}.o1.w"), c, c, bias=W[f"{n}.o1.b"], residual=h0, row_stats=self.folds(o, m, c, c))
         self.arena.free(o)
         self.arena.free(h0)
         # cross-attention (K/V of the prompt embeddings are per-call constants)
@@ -779,7 +856,7 @@ class HipEngine:
         kp = kv.data_ptr()
         o = self.attention(q2, c, kp, kp + 2 * c, 2 * c, batch, a.heads, hw, n_ctx, n_ctx)
         self.arena.free(q2)
-        h2 = self.linear(o, W[f"{n}.o2.w"], c, c, bias=W[f"{n}.o2.b"], residual=h1, row_stats=self.folds(o, m, c, 8 * c, True))
+        h2 = self.linear(o, self._Wl(f"{n}.o2.w"), c, c, bias=W[f"{n}.o2.b"], residual=h1, row_stats=self.folds(o, m, c, 8 * c, True))
         self.arena.free(o)
         self.arena.free(h1)
         # GEGLU feed-forward
@@ -821,7 +898,7 @@ class HipEngine:
         cd = self.ucfg.cross_attention_dim
         for a in self._attn_specs:
             t = torch.empty((batch * n_ctx, 2 * a.channels), dtype=self.tdt, device=self.device)
-            out[a.name] = self.linear(ctx, self.w[f"{a.name}.kv2.w"], 2 * a.channels, cd, out=t)
+            out[a.name] = self.linear(ctx, self._Wl(f"{a.name}.kv2.w"), 2 * a.channels, cd, out=t)
         return out
 
     def time_tables(self, timesteps: torch.Tensor) -> torch.Tensor:
@@ -851,6 +928,9 @@ class HipEngine:
         g, cfg, W = self.ugraph, self.ucfg, self.w
         b0, cin, h, w_ = lat.shape
         B = b0 * rep
+        self._rep = rep
+        if self.groups > 1 and b0 % self.groups:
+            raise ValueError(f"set_lora_groups({self.groups}) needs a batch that is a multiple of the group count, got {b0}")
         eps_n = cfg.norm_eps
         launches0 = self.lib.idb_launch_count()
         c0 = cfg.block_out_channels[0]
@@ -932,6 +1012,7 @@ class HipEngine:
         tp = self.time_tables(ts)
         ctx = self.cast(encoder_hidden_states.to(self.device).float().reshape(-1, encoder_hidden_states.shape[-1]))
         n_ctx = encoder_hidden_states.shape[1]
+        self._rep = 1                                  # API form: LoRA groups (if any) partition the GIVEN batch contiguously
         kv = self.cross_kv(ctx, B, n_ctx)
         eps = self.unet_nhwc(lat, 1, (tp, 0, self.tproj_total), kv, n_ctx)
         out = torch.empty((B, self.ucfg.out_channels, h, w_), dtype=torch.float32, device=self.device)
@@ -956,6 +1037,7 @@ class HipEngine:
         h, w_ = lat.shape[2], lat.shape[3]
         self.arena.reset()
         self._pinned.clear()
+        self._rep = rep
         lat.copy_(noise[0])                                  # init_noise_sigma = 1
         if hist is not None:
             hist.zero_()                                     # multistep solver: x0 history (coefficient 0 on the first step)
@@ -964,7 +1046,7 @@ class HipEngine:
         kv = {}
         cd = self.ucfg.cross_attention_dim
         for a in self._attn_specs:
-            kv[a.name] = self.linear(ctx, self.w[f"{a.name}.kv2.w"], 2 * a.channels, cd)
+            kv[a.name] = self.linear(ctx, self._Wl(f"{a.name}.kv2.w"), 2 * a.channels, cd)
             self._pinned.add(kv[a.name].data_ptr())
         self.arena.free(ctx)
         for i in range(steps):
@@ -1006,7 +1088,7 @@ class HipEngine:
             return lat
         if not hasattr(self, "_graphs"):
             self._graphs = {}
-        key = ("sample", B, lc, h, w_, steps, n_ctx, cfg_on, vpred, self.dtype_name, multistep)
+        key = ("sample", B, lc, h, w_, steps, n_ctx, cfg_on, vpred, self.dtype_name, multistep, self.groups)
         ent = self._graphs.get(key)
         if ent is None:
             ent = {"ctx": ctx_f32.clone(), "noise": noise.clone(), "coefs": coefs.clone(), "tp": tp.clone(),

@@ -210,7 +210,7 @@ class StableDiffusionPipeline:
             from .engine import HipEngine          # raises loudly if the HIP library is missing
             self._eng = HipEngine(self.unet_config, self.vae_config, self._unet_sd, self._vae_sd, self.device, self.dtype_name)
             if self._lora is not None:
-                self._eng.set_lora(*self._lora)
+                self._eng.set_lora_groups(*self._lora)
         return self._eng
 
     @property
@@ -259,6 +259,23 @@ class StableDiffusionPipeline:
     def load_lora_weights(self, pretrained_model_name_or_path_or_dict, weight_name: str = "pytorch_lora_weights.safetensors",
                           **kw) -> None:
         src = pretrained_model_name_or_path_or_dict
+        if isinstance(src, (list, tuple)):
+            # one adapter set per GROUP of the batch (group g = samples [g*B/G, (g+1)*B/G) of every call): a mixed-identity batch in
+            # one sampler call (BASELINE configs[2]: 8 identities x 8 prompts); each entry is what the single form accepts
+            sets = []
+            for one in src:
+                if isinstance(one, dict):
+                    sets.append((W.normalize_lora_keys(one), {}))
+                else:
+                    if not os.path.exists(one):
+                        raise FileNotFoundError(f"LoRA checkpoint {one!r} not found (local paths only)")
+                    sets.append(W.load_lora(one, weight_name))
+            if not sets or any(not t for t, _ in sets):
+                raise ValueError("no UNet LoRA tensors found in a checkpoint of the list")
+            self._lora = ([t for t, _ in sets], 1.0, sets[0][1])
+            if self._eng is not None:
+                self._eng.set_lora_groups(*self._lora)
+            return
         if isinstance(src, dict):
             tensors, alphas = W.normalize_lora_keys(src), {}
         else:
@@ -267,14 +284,14 @@ class StableDiffusionPipeline:
             tensors, alphas = W.load_lora(src, weight_name)
         if not tensors:
             raise ValueError("no UNet LoRA tensors found in the checkpoint")
-        self._lora = (tensors, 1.0, alphas)
+        self._lora = ([tensors], 1.0, alphas)
         if self._eng is not None:
-            self._eng.set_lora(*self._lora)
+            self._eng.set_lora_groups(*self._lora)
 
     def unload_lora_weights(self) -> None:
         self._lora = None
         if self._eng is not None:
-            self._eng.set_lora(None)
+            self._eng.set_lora_groups([None])
 
     # ---- sampling ---------------------------------------------------------------------
     def check_inputs(self, prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds):

@@ -120,6 +120,14 @@ typedef struct {
                                  [ceil(n/16)][K/64][16 rows][64 k]: the rows of one K-step of a column tile are whole 2 KiB runs and
                                  a workgroup's K loop reads each of its row blocks as ONE contiguous stream (HBM pages, TLB reach)
                                  instead of 128-byte pieces at a K*2-byte stride */
+    /* Grouped weights — a mixed-identity batch in ONE launch (BASELINE configs[2] = 8 identities x 8 prompts; per-row LoRA adapters of
+     * peft's lora.Linear, train_ID-Booth.py:672-678, in their MERGED form): `w` holds w_groups weight matrices of identical shape,
+     * w_group_stride bytes apart (each [n][K] rows or K-tiled as w_layout says); output row m uses matrix (m / w_group_rows) % w_groups.
+     * w_group_rows must be a multiple of the plan's tile height (idb_gemm returns IDB_EUNSUPPORTED otherwise: the caller then runs one
+     * launch per group).  With a folded LayerNorm, ln_u / ln_v hold w_groups vectors of n floats each.  0 or 1: one matrix. */
+    int32_t w_groups;
+    int32_t w_group_rows;
+    int64_t w_group_stride;
 } idb_gemm_desc;
 
 size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);

@@ -27,7 +27,8 @@ def test_bench_json_contract(lib):
     assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 0.05
     assert set(d["path"]["stages"]) >= {"sampling_loop_ms", "vae_decode_postprocess_ms", "d2h_uint8_ms"}
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "live_events", "source", "launches_per_cfg_forward_all_kernels"):
+    # achieved / frac / avg_launch_us: this run's live HIP-event figures; "profiled": the committed rocprofv3 summary (or null / stale)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "source", "profiled", "launches_per_cfg_forward_all_kernels"):
         assert k in r, k
     assert r["launches_per_cfg_forward_all_kernels"] > 100
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3

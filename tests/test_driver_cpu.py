@@ -156,3 +156,27 @@ def test_sink_writes_reference_layout(tmp_path):
     import numpy as np
     assert np.array_equal(np.array(Image.open(d / items[0].file_name())), imgs[0].numpy())
     assert Image.open(comp).size == (8 * 2, 8 * 2)          # nrow = num_prompts, one row per model
+
+
+def test_plan_calls_groups_identities_of_one_model_into_single_calls():
+    """BASELINE configs[2] as stated: 8 identities x 8 prompts -> ONE batch-64 call with 8 LoRA groups; the reference's own work list
+    (1 identity x 3 models x 21 prompts) stays three calls; order and stream offsets are kept inside every identity."""
+    ids = [f"ID_{i + 1}" for i in range(8)]
+    cfg = D.PolicyConfig(num_prompts=8, models_to_test=("ID-Booth",))
+    items = D.build_work_list(ids, {i: "M" for i in ids}, cfg)
+    calls = D.plan_calls(items, 64, 8)
+    assert len(calls) == 1 and [len(sub) for sub in calls[0]] == [8] * 8
+    assert [sub[0].which_id for sub in calls[0]] == ids and all([it.stream_offset for it in sub] == list(range(8)) for sub in calls[0])
+    assert [[it for it in sub] for sub in D.plan_calls(items, 64, 1)[0]] == [[it for it in items[:8]]] and len(D.plan_calls(items, 64, 1)) == 8
+    # a cap of 32 images per call: two calls of 4 identities
+    calls = D.plan_calls(items, 32, 8)
+    assert [len(c) for c in calls] == [4, 4] and sum(len(s) for c in calls for s in c) == 64
+    # 3 models x 21 prompts of one identity: nothing to group
+    cfg3 = D.PolicyConfig()
+    items3 = D.build_work_list(["ID_1"], {"ID_1": "F"}, cfg3)
+    calls3 = D.plan_calls(items3, 64, 8)
+    assert len(calls3) == 3 and all(len(c) == 1 and len(c[0]) == 21 for c in calls3)
+    # every item appears exactly once, whatever the grouping
+    for g in (1, 2, 8):
+        flat = [it for c in D.plan_calls(items, 64, g) for s in c for it in s]
+        assert sorted(map(id, flat)) == sorted(map(id, items))

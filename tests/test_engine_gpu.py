@@ -141,3 +141,46 @@ def test_pipeline_outputs_and_errors(pipe, models):
         pipe(prompt="x", output_type="np", **kw)
     with pytest.raises(NotImplementedError):
         pipe(prompt="face portrait photo of sks person", num_inference_steps=2, height=128, width=128)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_lora_groups_equal_per_identity_runs(lib, dtype):
+    """load_lora_weights([l0, l1, l2]): group g of the batch uses identity g's merged weights inside ONE sampler call (grouped weights in
+    idb_gemm, per-group fallback for the 77-token K/V projections).  Must equal the three single-identity calls on the same prompts
+    and noise; and a grouped UNet forward must equal the oracle's UNMERGED LoRA per sample."""
+    from faceposegenerator_amd import spec as S, weights as W
+    from faceposegenerator_amd.pipeline import StableDiffusionPipeline
+    from oracle import sd21_oracle as O
+    ucfg, vcfg = S.TINY_UNET, S.TINY_VAE
+    usd, vsd = W.synth_unet(ucfg, 7), W.synth_vae(vcfg, 8)
+    loras = [W.synth_lora(ucfg, seed=20 + i) for i in range(3)]
+    g = torch.Generator().manual_seed(9)
+    B, steps = 6, 3
+    pe, ne = torch.randn(B, 77, ucfg.cross_attention_dim, generator=g), torch.randn(B, 77, ucfg.cross_attention_dim, generator=g)
+    noise = torch.randn(steps + 1, B, 4, 16, 16, generator=g)
+    pipe = StableDiffusionPipeline(ucfg, vcfg, usd, vsd, torch_dtype=dtype).to(DEV)
+    pipe.load_lora_weights(loras)
+    kw = dict(num_inference_steps=steps, guidance_scale=5.0, height=128, width=128, output_type="latent")
+    mixed = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, noise=noise, **kw).images.cpu()
+    mixed2 = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, noise=noise, **kw).images.cpu()           # graph replay
+    assert torch.equal(mixed, mixed2)
+    tol = 2e-2 if dtype == "bf16" else 3e-3
+    for i, l in enumerate(loras):
+        pipe.load_lora_weights(l)
+        sl = slice(2 * i, 2 * i + 2)
+        single = pipe(prompt_embeds=pe[sl], negative_prompt_embeds=ne[sl], noise=noise[:, sl], **kw).images.cpu()
+        rel = ((mixed[sl] - single).norm() / single.norm()).item()
+        assert rel < tol, (i, rel)
+    # teacher-forced: grouped forward vs the oracle with each sample's own (unmerged) adapters
+    pipe.load_lora_weights(loras)
+    x = torch.randn(B, 4, 16, 16, generator=g)
+    eps = pipe.unet(x.to(DEV), 501, pe.to(DEV), return_dict=False)[0].cpu()
+    with torch.no_grad():
+        for i, l in enumerate(loras):
+            sl = slice(2 * i, 2 * i + 2)
+            ref = O.unet_forward(usd, ucfg, x[sl], 501, pe[sl], O.normalize_lora_keys(l))
+            rel = ((eps[sl] - ref).norm() / ref.norm()).item()
+            assert rel < (3e-2 if dtype == "bf16" else 4e-3), (i, rel)
+    # back to one identity: the grouped buffers stay allocated, the single path is used
+    pipe.load_lora_weights(loras[0])
+    assert pipe._engine().groups == 1
