@@ -19,7 +19,7 @@ IDB_MAX_SRC = 4
 # every symbol include/idb_kernels.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "idb_version", "idb_launch_count", "idb_last_error", "idb_device_check",
-    "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm_row_stats_tiles", "idb_gemm_folds_layernorm", "idb_gemm_emits_gn_partials", "idb_gemm",
+    "idb_gemm_workspace_bytes", "idb_gemm_plan", "idb_gemm_row_stats_tiles", "idb_gemm_folds_layernorm", "idb_gemm_fuses_groupnorm", "idb_gemm_emits_gn_partials", "idb_gemm",
     "idb_pack_conv_weight", "idb_pack_matrix", "idb_tiled_weight_bytes", "idb_tile_weight", "idb_lora_merge", "idb_lora_merge_scaled", "idb_pack_matrix_scaled", "idb_ln_fold_vectors",
     "idb_groupnorm_workspace_bytes", "idb_groupnorm", "idb_layernorm", "idb_groupnorm_stats",
     "idb_attention", "idb_embed_tokens", "idb_softmax_rows",
@@ -47,7 +47,9 @@ class GemmDesc(C.Structure):
                 ("counters", C.c_void_p), ("counters_len", C.c_int32), ("gn_partials", C.c_void_p), ("gn_groups", C.c_int32),
                 ("row_stats_out", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_tiles", C.c_int32), ("ln_u", C.c_void_p),
                 ("ln_v", C.c_void_p), ("ln_eps", C.c_float), ("pad_mode", C.c_int32), ("w_layout", C.c_int32),
-                ("w_groups", C.c_int32), ("w_group_rows", C.c_int32), ("w_group_stride", C.c_int64)]
+                ("w_groups", C.c_int32), ("w_group_rows", C.c_int32), ("w_group_stride", C.c_int64),
+                ("gn_in_partials", C.c_void_p), ("gn_in_chunks", C.c_int32), ("gn_in_groups", C.c_int32), ("gn_in_nsrc", C.c_int32),
+                ("gn_in_silu", C.c_int32), ("gn_in_eps", C.c_float), ("gn_in_gamma", C.c_void_p), ("gn_in_beta", C.c_void_p)]
 
 
 class GemmFp8Desc(C.Structure):
@@ -85,6 +87,7 @@ def load() -> C.CDLL:
         "idb_gemm": (C.c_int, [C.POINTER(GemmDesc), vp, sz, vp]),
         "idb_gemm_row_stats_tiles": (i32, [C.POINTER(GemmDesc)]),
         "idb_gemm_folds_layernorm": (i32, [C.POINTER(GemmDesc)]),
+        "idb_gemm_fuses_groupnorm": (i32, [C.POINTER(GemmDesc)]),
         "idb_gemm_emits_gn_partials": (i32, [C.POINTER(GemmDesc), i32]),
         "idb_lora_merge_scaled": (C.c_int, [vp, vp, vp, vp, i64, i64, i32, f32, vp, i32, vp]),
         "idb_pack_conv_weight": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),

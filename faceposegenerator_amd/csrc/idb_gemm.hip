@@ -420,6 +420,325 @@ __global__ __launch_bounds__(128 * WM + 64 * LW) void idb_gemm_kernel_lw(const G
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU) -> conv / linear in ONE kernel (round 3; north_star "conv3x3 + GroupNorm+SiLU fused"; diffusers ResnetBlock2D
+// norm1+conv1, norm2+conv2(+shortcut), Transformer2DModel norm+proj_in via inference_ID-Booth.py:138) on the loader-wave structure:
+// a THIRD role, NV normalizer waves, transforms each landed A stage in place in LDS — y = silu(x * k[b][c] + h[b][c]), the exact
+// arithmetic of gn_apply_kernel (k = rstd * gamma, h = beta - mean * k from the same partial sums, added in the same order, so the
+// MFMA waves read bit-identical operands) — one K-step ahead of the MFMA waves.  The normalised tensor never exists in HBM and the
+// gn_apply launch (60 per CFG forward, 6.4 us each at batch 1) disappears.  Round 2's idb_hconv did this transform on the MFMA
+// waves themselves and lost; here it runs on waves that do nothing else, so the MFMA waves' stream is unchanged.
+//   roles (wave index): [0, 2*WM) MFMA, [2*WM, 2*WM + 4) loaders, then NV normalizers.  Every wave passes the same barriers:
+//   two while the normalizers build the {k, h} table in LDS (group statistics, then per channel), one that publishes the
+//   normalised stage 0, then one per K-step.  Ring of NS stages: at K-step `it` the MFMA waves read stage it, the normalizers
+//   transform stage it+1 (landed: the loaders waited for it before the barrier), stages it+2 .. are in flight.
+//   Zero padding stays zero: rows whose tap falls outside the image are skipped (silu(h) != 0).  Sources beyond gn_in_nsrc (the
+//   raw inputs of a fused 1x1 shortcut) pass untouched.  A tile lies inside one sample, or covers whole samples (host check).
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int MF, int NF, int NS, int WM, int NV>
+__global__ __launch_bounds__(128 * WM + 256 + 64 * NV) void idb_gemm_kernel_gn(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using V8 = typename Op<T>::v8;
+    constexpr int LW = 4;
+    constexpr int BM = 16 * MF * WM, BN = 32 * NF;
+    constexpr int CT = 128 * WM, LT = 64 * LW, VT = 64 * NV;
+    constexpr int LR = 8 * LW;
+    constexpr int NA = BM / LR, NJ = (BN + LR - 1) / LR;
+    constexpr int STAGE = (BM + NJ * LR) * 128;
+    constexpr int LOADS = NA + NJ;
+    constexpr int NI = BM * 8 / VT;                            // 16-byte items of an A stage per normalizer lane
+    static_assert(BM % LR == 0 && (BM * 8) % VT == 0, "tile / role geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* tab = (float2*)(smem + NS * STAGE);                // [nsamp][gn_in_c] {k, h}
+    const int hw_s = p.HW;
+    const int nsamp = BM > hw_s ? BM / hw_s : 1;               // host: HW % BM == 0 or BM % HW == 0
+    float2* gstat = tab + nsamp * p.gn_in_c;                   // [nsamp][groups] {mean, rstd}
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int wg, kz;
+    if (p.xcd_mode == 0) {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        kz = blockIdx.z;
+    } else {
+        const int X = gridDim.x;
+        const int lin = blockIdx.x + X * blockIdx.z;
+        const int xcd = lin & 7, j = lin >> 3;
+        if (p.xcd_mode == 1) {
+            kz = xcd + 8 * (j / X);
+            wg = j % X;
+        } else {
+            kz = xcd >> 1;
+            wg = (xcd & 1) * (X >> 1) + j;
+        }
+    }
+    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt0 = (int)(((long long)kz * p.ktiles) / p.splitk);
+    const int kt1 = (int)(((long long)(kz + 1) * p.ktiles) / p.splitk);
+    const int nk = kt1 - kt0;
+
+    // K-step cursor shared by loaders and normalizers: source s, tap, channel offset c0
+    int s = 0, tap = 0, c0 = 0;
+    {
+        int rem = kt0;
+        while (s < IDB_MAX_SRC - 1) {
+            const int steps = p.src[s].taps * (p.src[s].C >> 6);
+            if (rem < steps) break;
+            rem -= steps;
+            ++s;
+        }
+        const int cs = p.src[s].C >> 6;
+        if (p.src[s].taps == 9) {
+            tap = rem / cs;
+            c0 = (rem - tap * cs) << 6;
+        } else {
+            tap = 4;
+            c0 = rem << 6;
+        }
+    }
+    auto advance = [&]() {                                     // to the next K-step
+        c0 += 64;
+        if (c0 == p.src[s].C) {
+            c0 = 0;
+            if (++tap == (p.src[s].taps == 9 ? 9 : 5)) {
+                if (s < IDB_MAX_SRC - 1) ++s;
+                tap = p.src[s].taps == 9 ? 0 : 4;
+            }
+        }
+    };
+
+    if (wave >= 2 * WM + LW) {
+        // ---------------- normalizer waves ----------------
+        const int nt = tid - CT - LT;
+        const int b_first = m0 / hw_s;
+        const int G = p.gn_in_groups, cpg = p.gn_in_c / G;
+        // phase 1: {mean, rstd} per (sample, group): 8 lanes per pair add the pixel-chunk partials in gn_apply_kernel's order
+        for (int pr0 = 0; pr0 < nsamp * G; pr0 += VT / 8) {
+            const int pr = pr0 + (nt >> 3), sub = nt & 7;
+            const int prc = min(pr, nsamp * G - 1);
+            const int sm = prc / G, g = prc - sm * G;
+            const int b = min(b_first + sm, (p.M - 1) / hw_s);
+            f32x2 pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ch = min(sub + 8 * u, p.gn_in_chunks - 1);
+                pv[u] = *(const f32x2*)(p.gn_in_part + (((long long)b * p.gn_in_chunks + ch) * G + g) * 2);
+            }
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (sub + 8 * u < p.gn_in_chunks) {
+                    a += pv[u][0];
+                    q += pv[u][1];
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if (pr < nsamp * G && sub == 0) {
+                const double cnt = (double)hw_s * cpg;
+                const double mean = (double)a / cnt;
+                double var = (double)q / cnt - mean * mean;
+                if (var < 0.0) var = 0.0;
+                gstat[pr] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gn_in_eps)));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // barrier A
+        // phase 2: k = rstd * gamma, h = beta - mean * k per (sample, channel)
+        for (int i = nt; i < nsamp * p.gn_in_c; i += VT) {
+            const int sm = i / p.gn_in_c, c = i - sm * p.gn_in_c;
+            const float2 st = gstat[sm * G + c / cpg];
+            const float k = st.y * p.gn_in_gamma[c];
+            tab[i] = make_float2(k, p.gn_in_beta[c] - st.x * k);
+        }
+        // rows of this lane's items: item j = row j * (VT / 8) + (nt >> 3), LDS chunk position nt & 7
+        int r_b[NI], r_oy[NI], r_ox[NI];
+        bool r_ok[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int row = j * (VT / 8) + (nt >> 3);
+            const int m = m0 + row;
+            r_ok[j] = m < p.M;
+            const int mm = r_ok[j] ? m : 0;
+            r_b[j] = mm / hw_s;
+            const int rem = mm - r_b[j] * hw_s;
+            r_oy[j] = rem / p.OW;
+            r_ox[j] = rem - r_oy[j] * p.OW;
+            r_b[j] -= b_first;
+        }
+        int cb = 0;                                            // first channel of source s inside the normalised concatenation
+        for (int q = 0; q < s; ++q) cb += p.src[q].C;
+        int s_seen = s;
+        const int pos = nt & 7;
+        auto transform = [&](int buf) {
+            if (s != s_seen) {                                 // entered the next source
+                cb += p.src[s_seen].C;
+                s_seen = s;
+            }
+            if (s < p.gn_in_nsrc) {
+                const GemmSrcK S = p.src[s];
+                const int t3 = tap / 3;
+                const int dy = t3 - p.pad, dx = tap - t3 * 3 - p.pad;
+                const int LH = S.H << S.up, LWd = S.W << S.up;
+                char* sA = smem + buf * STAGE;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int row = j * (VT / 8) + (nt >> 3);
+                    const int iy = r_oy[j] * p.stride + dy, ix = r_ox[j] * p.stride + dx;
+                    const bool ok = r_ok[j] && (S.taps == 1 || ((unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LWd));
+                    if (ok) {
+                        const int c = cb + c0 + 8 * (pos ^ (row & 7));
+                        const f32x4* tp = (const f32x4*)(tab + r_b[j] * p.gn_in_c + c);
+                        const f32x4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3v = tp[3];      // {k,h} x 8 channels
+                        V8* px = (V8*)(sA + row * 128 + pos * 16);
+                        const V8 raw = *px;
+                        const float ks[8] = {t0[0], t0[2], t1[0], t1[2], t2[0], t2[2], t3v[0], t3v[2]};
+                        const float kh[8] = {t0[1], t0[3], t1[1], t1[3], t2[1], t2[3], t3v[1], t3v[3]};
+                        V8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float y = to_f32<T>(raw[e]) * ks[e] + kh[e];
+                            if (p.gn_in_silu) y = silu_f(y);
+                            o[e] = from_f32<T>(y);
+                        }
+                        *px = o;
+                    }
+                }
+            }
+            advance();
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // barrier B: table complete, stage 0 landed
+        if (nk > 0) transform(0);
+        int cur = 0;
+        for (int it = 0; it < nk; ++it) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // barrier C_it
+            const int nxt = cur + 1 == NS ? 0 : cur + 1;
+            if (it + 1 < nk) transform(nxt);
+            cur = nxt;
+        }
+        return;
+    }
+
+    if (wave >= 2 * WM) {
+        // ---------------- loader waves ----------------
+        const int lw = wave - 2 * WM;
+        const int lt = tid - CT;
+        const int lrow = lt >> 3;
+        const unsigned cg16 = ((lt & 7) ^ (lrow & 7)) * 16;
+        int a_b[NA], a_oy[NA], a_ox[NA];
+        bool a_ok[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + i * LR + lrow;
+            a_ok[i] = m < p.M;
+            const int mm = a_ok[i] ? m : 0;
+            a_b[i] = mm / p.HW;
+            const int rem = mm - a_b[i] * p.HW;
+            a_oy[i] = rem / p.OW;
+            a_ox[i] = rem - a_oy[i] * p.OW;
+        }
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + idb_weight_group(p, m0) * p.w_group_stride), 0, p.w_bytes, IDB_RSRC_FLAGS);
+        unsigned w_voff[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + j * LR + lrow;
+            w_voff[j] = (n < p.N && j * LR + lrow < BN) ? (unsigned)(n >> 4) * p.w_blk_bytes + (unsigned)(n & 15) * p.w_row_bytes + cg16 : IDB_OOB;
+        }
+        unsigned w_soff = (unsigned)kt0 * p.w_kstep;
+        __amdgpu_buffer_rsrc_t rs_a = rs_w;
+        unsigned a_voff[NA];
+        int last_s = -1, last_tap = -1;
+        auto stage = [&](int buf) {
+            char* sA = smem + buf * STAGE;
+            char* sB = sA + BM * 128;
+            if (s != last_s || tap != last_tap) {
+                const GemmSrcK S = p.src[s];
+                rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)S.ptr, 0, S.bytes, IDB_RSRC_FLAGS);
+                const int t3 = tap / 3;
+                const int dy = t3 - p.pad, dx = tap - t3 * 3 - p.pad;
+                const int LH = S.H << S.up, LWd = S.W << S.up;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
+                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)LH && (unsigned)ix < (unsigned)LWd;
+                    const int pix = (a_b[i] * S.H + (iy >> S.up)) * S.W + (ix >> S.up);
+                    a_voff[i] = ok ? (unsigned)pix * (unsigned)(S.C * 2) + cg16 : IDB_OOB;
+                }
+                last_s = s;
+                last_tap = tap;
+            }
+            const unsigned a_soff = (unsigned)c0 * 2u;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(sA + (i * 64 * LW + lw * 64) * 16), 16, a_voff[i], a_soff, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + (j * 64 * LW + lw * 64) * 16), 16, w_voff[j], w_soff, 0, 0);
+            w_soff += p.w_kstep;
+            advance();
+        };
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st)
+            if (st < nk) stage(st);
+        asm volatile("s_barrier" ::: "memory");                                             // barrier A
+        if (NS - 1 <= nk)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * LOADS) : "memory");   // barrier B: stage 0 landed
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        int cur = 0;
+        for (int it = 0; it < nk; ++it) {
+            // stage it+1 landed (the normalizers transform it next); stages it+2 .. it+NS-2 stay in flight
+            if (it + NS - 2 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 3) * LOADS) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (it + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1);
+            cur = cur + 1 == NS ? 0 : cur + 1;
+        }
+        return;
+    }
+
+    // ---------------- MFMA waves ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_barrier" ::: "memory");                                                 // barrier A
+    asm volatile("s_barrier" ::: "memory");                                                 // barrier B
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     // barrier C_it
+        const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
+        const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pos = ((ks * 4 + fg) ^ (fr & 7)) * 16;
+            V8 af[MF], wf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const V8*)(sA + i * 16 * 128 + pos);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *(const V8*)(sB + j * 16 * 128 + pos);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
+        }
+        cur = cur + 1 == NS ? 0 : cur + 1;
+    }
+    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, kz, false, make_float2(0.f, 0.f));
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Register-staged variant: identical tiling, addressing and epilogue, but the operands go HBM/L2 -> VGPR
 // (buffer_load_dwordx4, asynchronous until its first use) -> LDS (ds_write_b128 after the MFMAs of the current
@@ -1093,6 +1412,47 @@ int launch_tile_lw(const GemmParams& p, const Plan& pl, hipStream_t st) {
     return IDB_OK;
 }
 
+// fused GroupNorm: LDS = ring + {k, h} table + group statistics; 0 if the shape cannot run (caller: IDB_EUNSUPPORTED)
+static size_t gn_fused_lds(int bm, int stage_rows, int ns, const GemmParams& p) {
+    const int nsamp = bm > p.HW ? bm / p.HW : 1;
+    return (size_t)stage_rows * 128 * ns + (size_t)nsamp * p.gn_in_c * 8 + (size_t)nsamp * p.gn_in_groups * 8;
+}
+
+template <typename T, int MF, int NF, int NS, int WM>
+int launch_tile_gn(const GemmParams& p, const Plan& pl, hipStream_t st) {
+    constexpr int NV = 4, LR = 32, NJ = (32 * NF + LR - 1) / LR, BM = 16 * MF * WM;
+    const size_t lds = gn_fused_lds(BM, BM + NJ * LR, NS, p);
+    if (lds > 160 * 1024) {
+        idb_set_error("idb_gemm: fused GroupNorm needs %zu bytes of LDS for this tile", lds);
+        return IDB_EUNSUPPORTED;
+    }
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_gemm_kernel_gn<T, MF, NF, NS, WM, NV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            idb_set_error("idb_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return IDB_EHIP;
+        }
+        attr_lds = 160 * 1024;
+    }
+    dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.splitk);
+    hipLaunchKernelGGL((idb_gemm_kernel_gn<T, MF, NF, NS, WM, NV>), grid, dim3(128 * WM + 256 + 64 * NV), lds, st, p);
+    IDB_CHECK_LAUNCH("idb_gemm(gn)");
+    return IDB_OK;
+}
+
+template <typename T>
+int launch_gn_by_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
+    switch (pl.tile % 10) {       // 64-row tiles: 4-stage ring; 128-row tiles: 3 stages (LDS)
+        case 4: return launch_tile_gn<T, 1, 2, 4, 4>(p, pl, st);
+        case 6: return launch_tile_gn<T, 1, 5, 4, 4>(p, pl, st);
+        case 7: return launch_tile_gn<T, 1, 4, 4, 4>(p, pl, st);
+        case 8: return launch_tile_gn<T, 2, 5, 3, 4>(p, pl, st);
+        default: return launch_tile_gn<T, 2, 4, 3, 4>(p, pl, st);
+    }
+}
+
 template <typename T, int NS, int LW>
 int launch_lw_by_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
     switch (pl.tile % 10) {
@@ -1145,6 +1505,11 @@ int launch_tile_pl(const GemmParams& p, const Plan& pl, hipStream_t st) {
 template <typename T>
 int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
     int rc;
+    if (p.gn_in_part) {
+        rc = launch_gn_by_tile<T>(p, pl, st);
+        if (rc != IDB_OK || (d->flags & 1)) return rc;
+        return idb_finish_splitk<T>(p, pl.M, d->n, d->batch, pl.splitk, d->gn_partials, d->gn_groups, d->dtype, st);
+    }
     if (pl.tile / 10 >= 5) {
         if (pl.tile / 10 == 8)
             rc = pl.tile % 10 == 8 ? launch_tile_lw<T, 4, 5, 3, 4, 4>(p, pl, st) : launch_tile_lw<T, 4, 4, 3, 4, 4>(p, pl, st);
@@ -1226,6 +1591,31 @@ extern "C" int32_t idb_gemm_emits_gn_partials(const idb_gemm_desc* d, int32_t gr
     if (plan_gemm(d, &pl) != IDB_OK) return 0;
     if (pl.splitk > 1) return d->out_dtype == d->dtype && pl.M % 64 == 0 && gn_reduce_slice(d->n, groups) != 0 ? 1 : 0;
     return gemm_epilogue_emits_gn(d, pl, groups) ? 2 : 0;
+}
+
+// the fused GroupNorm runs on the one-workgroup-per-CU loader-wave plans only (variants 5-7), stride 1, every normalised source on
+// the output grid, tiles inside one sample or covering whole samples, no folded LayerNorm on the same launch
+static bool gemm_fuses_gn(const idb_gemm_desc* d, const Plan& pl) {
+    if (!d->gn_in_partials) return false;
+    if (pl.tile / 10 < 5 || pl.tile / 10 > 7 || d->stride != 1 || d->ln_stats || d->geglu || d->gn_in_nsrc < 1 || d->gn_in_nsrc > d->nsrc) return false;
+    const int bm = 16 * kTiles[pl.tile % 10].mf * kTiles[pl.tile % 10].wm;
+    const long long hw = (long long)d->out_h * d->out_w;
+    if (!(hw % bm == 0 || (bm % hw == 0 && bm / hw <= 2))) return false;
+    long long cn = 0;
+    for (int s = 0; s < d->gn_in_nsrc; ++s) {
+        if (d->src[s].upsample || d->src[s].in_h != d->out_h || d->src[s].in_w != d->out_w) return false;
+        cn += d->src[s].channels;
+    }
+    if (d->gn_in_groups <= 0 || cn % d->gn_in_groups || cn / d->gn_in_groups < 1 || d->gn_in_chunks < 1 || d->gn_in_chunks > 64) return false;
+    const int nsamp = bm > hw ? (int)(bm / hw) : 1;
+    const int stage_rows = bm + (32 * kTiles[pl.tile % 10].nf + 31) / 32 * 32;
+    const size_t lds = (size_t)stage_rows * 128 * (bm == 64 ? 4 : 3) + (size_t)nsamp * cn * 8 + (size_t)nsamp * d->gn_in_groups * 8;
+    return lds <= 160 * 1024;
+}
+
+extern "C" int32_t idb_gemm_fuses_groupnorm(const idb_gemm_desc* d) {
+    Plan pl;
+    return plan_gemm(d, &pl) == IDB_OK && gemm_fuses_gn(d, pl) ? 1 : 0;
 }
 
 extern "C" int32_t idb_gemm_folds_layernorm(const idb_gemm_desc* d) {
@@ -1340,6 +1730,24 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     if (d->gn_partials && pl.splitk == 1 && !(d->flags & 1) && gemm_epilogue_emits_gn(d, pl, d->gn_groups)) {
         p.gn_part = d->gn_partials;          // launch_all's idb_finish_splitk then has nothing left to launch
         p.gn_groups = d->gn_groups;
+    }
+    if (d->gn_in_partials) {
+        if (!gemm_fuses_gn(d, pl)) {
+            idb_set_error("idb_gemm: this plan cannot fuse the GroupNorm (needs a one-workgroup-per-CU loader-wave plan, stride 1, sources on the "
+                          "output grid, tile inside one sample): run idb_groupnorm + idb_gemm");
+            return IDB_EUNSUPPORTED;
+        }
+        IDB_REQUIRE(d->gn_in_gamma && d->gn_in_beta && d->gn_in_eps > 0.f && idb_aligned16(d->gn_in_partials), "idb_gemm: gn_in_gamma / gn_in_beta / gn_in_eps invalid");
+        p.gn_in_part = d->gn_in_partials;
+        p.gn_in_gamma = d->gn_in_gamma;
+        p.gn_in_beta = d->gn_in_beta;
+        p.gn_in_chunks = d->gn_in_chunks;
+        p.gn_in_groups = d->gn_in_groups;
+        p.gn_in_nsrc = d->gn_in_nsrc;
+        p.gn_in_silu = d->gn_in_silu;
+        p.gn_in_eps = d->gn_in_eps;
+        p.gn_in_c = 0;
+        for (int s = 0; s < d->gn_in_nsrc; ++s) p.gn_in_c += d->src[s].channels;
     }
     p.w_groups = d->w_groups > 1 ? d->w_groups : 1;
     p.w_group_rows = d->w_group_rows;

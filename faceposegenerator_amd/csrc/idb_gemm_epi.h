@@ -46,6 +46,13 @@ struct GemmParams {
     // grouped weights (idb_gemm_desc.w_groups): tile rows [m0, m0 + BM) use matrix (m0 / w_group_rows) % w_groups
     int w_groups, w_group_rows;
     long long w_group_stride;
+    // GroupNorm(+SiLU) of the first gn_nsrc sources applied by normalizer waves inside the kernel (idb_gemm_kernel_gn): statistics as
+    // idb_groupnorm's partials_in over the channel concatenation of those sources, gamma / beta over the same channels
+    const float* gn_in_part;
+    const float* gn_in_gamma;
+    const float* gn_in_beta;
+    int gn_in_chunks, gn_in_groups, gn_in_nsrc, gn_in_silu, gn_in_c;      // gn_in_c: channels of the normalised concatenation
+    float gn_in_eps;
 };
 
 // byte offset of the weight matrix (and element offset of its folded-LayerNorm vectors) a tile uses

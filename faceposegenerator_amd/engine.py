@@ -126,6 +126,10 @@ class HipEngine:
         self._fold_cache: Dict[Tuple[int, int, int, bool], bool] = {}
         self._ff_chunk_bytes = int(os.environ.get("IDB_FF_CHUNK_MB", "160")) << 20       # 0: the feed-forward in one piece
         self._gn_epi = os.environ.get("IDB_GN_EPILOGUE", "1") != "0"      # GroupNorm statistics from non-split GEMM epilogues
+        # GroupNorm(+SiLU) applied by normalizer waves inside the consuming conv / proj_in (idb_gemm_desc.gn_in_*) wherever the plan is a
+        # one-workgroup-per-CU loader-wave plan (the batch-1 UNet); IDB_GN_CONV=0: idb_groupnorm + idb_gemm everywhere
+        self._gn_conv = os.environ.get("IDB_GN_CONV", "1") != "0" and dtype != "fp8"
+        self._gn_conv_cache: Dict[tuple, bool] = {}
         # weights in the K-tiled 16-row-block layout (idb_tile_weight): a workgroup's K loop reads each of its row blocks as one
         # contiguous stream instead of 128-byte pieces at a K*2-byte stride; IDB_W_TILED=0 keeps [n][K] rows
         self._w_tiled = os.environ.get("IDB_W_TILED", "1") != "0"
@@ -183,7 +187,7 @@ class HipEngine:
         for key, t in list(self.w.items()):
             if key in self.w_rows or getattr(t, "_tiled", None) is not None or key.endswith("attentions.0.v.w"):
                 continue                                  # (the VAE attention's to_v matrix is used as an A operand: rows)
-            if t.dtype == self.tdt and t.ndim == 2 and (key.endswith(".w") or key.endswith(".wln")) and t.shape[1] % 64 == 0:
+            if t.dtype == self.tdt and t.ndim == 2 and (key.endswith(".w") or key.endswith(".wln") or key.endswith(".wsplit")) and t.shape[1] % 64 == 0:
                 self.w[key] = self.tile_weight(t.contiguous())
 
     def tile_weight(self, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -203,13 +207,17 @@ class HipEngine:
         blk, t = p // 32, p % 32
         return torch.where(t < 16, 16 * blk + t, rows // 2 + 16 * blk + (t - 16))
 
-    def _pack_resnet(self, sd: SD, name: str, has_temb: bool) -> None:
+    def _pack_resnet(self, sd: SD, name: str, has_temb: bool, split_at: int = 0) -> None:
         w = self.w
         for i in ("1", "2"):
             w[f"{name}.gn{i}.g"] = self._f32(sd[f"{name}.norm{i}.weight"])
             w[f"{name}.gn{i}.b"] = self._f32(sd[f"{name}.norm{i}.bias"])
         w[f"{name}.conv1.w"] = self._pack_conv(sd[f"{name}.conv1.weight"])
         w[f"{name}.conv1.b"] = self._f32(sd[f"{name}.conv1.bias"])
+        if split_at:                                    # up-path resnet: norm1 + conv1 over cat[x, skip] as TWO 3x3 sources (fused GroupNorm)
+            w1 = sd[f"{name}.conv1.weight"]
+            w[f"{name}.conv1.wsplit"] = torch.cat([self._pack_conv(w1[:, :split_at].contiguous()), self._pack_conv(w1[:, split_at:].contiguous())],
+                                                  dim=1).contiguous()
         w2 = self._pack_conv(sd[f"{name}.conv2.weight"])
         b2 = self._f32(sd[f"{name}.conv2.bias"])
         if self.fp8 and has_temb:                       # UNet resnets: e4m3 copies of the two 3x3 convs, the 1x1 shortcut stays f16
@@ -253,7 +261,7 @@ class HipEngine:
                 w[blk["up"] + ".b"] = self._f32(sd[blk["up"] + ".bias"])
         tw, tb, off = [], [], 0
         for r in resnets:
-            self._pack_resnet(sd, r.name, True)
+            self._pack_resnet(sd, r.name, True, split_at=(r.cin - r.skip_channels) if getattr(r, "skip_channels", 0) else 0)
             self.tproj_off[r.name] = off
             tw.append(sd[f"{r.name}.time_emb_proj.weight"])
             tb.append(sd[f"{r.name}.time_emb_proj.bias"])
@@ -501,7 +509,7 @@ class HipEngine:
     def gemm(self, srcs, w: torch.Tensor, n: int, batch: int, oh: int, ow: int, bias=None, sbias=None,
              residual=None, geglu=False, stride=1, out_f32=False, out_scale=0.0, split_k=0, tile=0,
              out: Optional[torch.Tensor] = None, flags: int = 0, act: int = 0, pad_mode: int = 0, gn_stats: int = 0,
-             gn_stats_always: bool = False, row_stats: bool = False, ln=None) -> torch.Tensor:
+             gn_stats_always: bool = False, row_stats: bool = False, ln=None, gn_in=None) -> torch.Tensor:
         """srcs: list of (tensor, channels, taps, in_h, in_w, upsample); sbias: (tensor, elem_offset, ld).
         row_stats: also emit the per-row partial sums a folded LayerNorm of the output needs (``out._rs = (buffer, tiles)``) when the
         plan can; ln = (stats, tiles, u, v, eps): A holds raw rows, w the gamma-scaled weights (idb_gemm_desc.ln_*)."""
@@ -523,6 +531,9 @@ class HipEngine:
         d.out, d.out_dtype, d.out_ld = out.data_ptr(), (L.IDB_F32 if out_f32 else self.dt), out.shape[-1]
         d.split_k, d.tile, d.out_scale, d.flags, d.act = split_k, tile, out_scale, flags, act
         d.pad_mode = pad_mode
+        if gn_in is not None:       # (partials, chunks, groups, eps, gamma, beta, silu, nsrc): GroupNorm(+SiLU) of the first nsrc sources in-kernel
+            d.gn_in_partials, d.gn_in_chunks, d.gn_in_groups, d.gn_in_eps = gn_in[0].data_ptr(), gn_in[1], gn_in[2], gn_in[3]
+            d.gn_in_gamma, d.gn_in_beta, d.gn_in_silu, d.gn_in_nsrc = gn_in[4].data_ptr(), gn_in[5].data_ptr(), int(gn_in[6]), gn_in[7]
         d.w_layout = 1 if getattr(w, "_tiled", None) is not None else 0
         G = getattr(w, "_groups", 0) or 0
         if G > 1:                                      # grouped weights: rows [r*M/rep + g*rpg, ... + rpg) of every CFG half r use matrix g
@@ -530,6 +541,16 @@ class HipEngine:
             if m % (rep * G):
                 raise ValueError(f"grouped weights: {m} rows do not divide into {rep} x {G} groups")
             d.w_groups, d.w_group_rows, d.w_group_stride = G, m // (rep * G), w.shape[1] * 2
+            tile_id = C.c_int32()
+            L.check(self.lib.idb_gemm_plan(C.byref(d), C.byref(tile_id), None, None), "idb_gemm_plan")
+            bm = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128, 6: 64, 7: 64, 8: 128, 9: 128}[tile_id.value % 10] * (2 if tile_id.value // 10 == 8 else 1)
+            if tile_id.value // 10 == 4 or d.w_group_rows % bm:
+                # this launch will run group by group on row slices (_gemm_per_group): no row statistics out, no folded LayerNorm in
+                row_stats = False
+                if ln is not None:
+                    if own_out:
+                        self.arena.free(out)
+                    return None
         rs_buf = None
         if row_stats and self._ln_fold:
             nt = self.lib.idb_gemm_row_stats_tiles(C.byref(d))
@@ -604,6 +625,26 @@ class HipEngine:
             need_j = self.lib.idb_gemm_workspace_bytes(C.byref(d))
             wsj = self._workspace(need_j) if need_j else None
             L.check(self.lib.idb_gemm(C.byref(d), _ptr(wsj), need_j, _stream()), "idb_gemm (per group)")
+
+    def fuses_groupnorm(self, src_shapes, w: torch.Tensor, n: int, batch: int, oh: int, ow: int, groups: int, nsrc_norm: int) -> bool:
+        """Would idb_gemm apply the GroupNorm of the first `nsrc_norm` sources inside the kernel for this shape?  src_shapes:
+        [(channels, taps)].  Host-only (plan query), cached per shape."""
+        if not self._gn_conv:
+            return False
+        key = (tuple(src_shapes), n, batch, oh, ow, groups, nsrc_norm, getattr(w, "_tiled", None) is not None)
+        hit = self._gn_conv_cache.get(key)
+        if hit is None:
+            d = L.GemmDesc()
+            dummy = self._gn_ws.data_ptr()
+            d.dtype, d.batch, d.out_h, d.out_w, d.stride, d.n, d.nsrc = self.dt, batch, oh, ow, 1, n, len(src_shapes)
+            for i, (ch, taps) in enumerate(src_shapes):
+                d.src[i].ptr, d.src[i].channels, d.src[i].taps, d.src[i].in_h, d.src[i].in_w = dummy, ch, taps, oh, ow
+            d.w, d.out, d.out_dtype, d.out_ld = dummy, dummy, self.dt, n
+            d.w_layout = 1 if getattr(w, "_tiled", None) is not None else 0
+            d.gn_in_partials, d.gn_in_chunks, d.gn_in_groups, d.gn_in_eps, d.gn_in_nsrc = dummy, 1, groups, 1e-5, nsrc_norm
+            d.gn_in_gamma = d.gn_in_beta = dummy
+            hit = self._gn_conv_cache[key] = self.lib.idb_gemm_fuses_groupnorm(C.byref(d)) > 0
+        return hit
 
     def linear(self, x: torch.Tensor, w: torch.Tensor, n: int, k: int, **kw) -> torch.Tensor:
         m = x.numel() // k
@@ -813,15 +854,39 @@ class HipEngine:
             if short:
                 self.arena.free(res)
             return out
-        n1 = self.groupnorm(xa, ca, xb, cb, batch, h * w_, W[f"{name}.gn1.g"], W[f"{name}.gn1.b"], eps, True, groups)
         sb = None if sbias is None else (sbias[0], sbias[1] + self.tproj_off[name], sbias[2])
         G = groups or self.ucfg.norm_num_groups
-        h1 = self.gemm([(n1, cin, 9, h, w_, 0)], W[f"{name}.conv1.w"], cout, batch, h, w_, bias=W[f"{name}.conv1.b"], sbias=sb,
-                       gn_stats=G)                       # norm2 consumes h1 next
-        self.arena.free(n1)
-        n2 = self.groupnorm(h1, cout, None, 0, batch, h * w_, W[f"{name}.gn2.g"], W[f"{name}.gn2.b"], eps, True, groups)
+        hw = h * w_
+        # ---- norm1 + SiLU + conv1: inside the conv (normalizer waves) where the plan allows, else idb_groupnorm + idb_gemm
+        w1 = W.get(f"{name}.conv1.wsplit") if xb is not None else W[f"{name}.conv1.w"]
+        shapes1 = [(ca, 9)] + ([(cb, 9)] if xb is not None else [])
+        if w1 is not None and self.fuses_groupnorm(shapes1, w1, cout, batch, h, w_, G, len(shapes1)):
+            part, chunks = self.gn_statistics(xa, ca, xb, cb, batch, hw, G)
+            srcs1 = [(xa, ca, 9, h, w_, 0)] + ([(xb, cb, 9, h, w_, 0)] if xb is not None else [])
+            h1 = self.gemm(srcs1, w1, cout, batch, h, w_, bias=W[f"{name}.conv1.b"], sbias=sb, gn_stats=G,
+                           gn_in=(part, chunks, G, eps, W[f"{name}.gn1.g"], W[f"{name}.gn1.b"], True, len(srcs1)))
+            self.arena.free(part)
+        else:
+            n1 = self.groupnorm(xa, ca, xb, cb, batch, hw, W[f"{name}.gn1.g"], W[f"{name}.gn1.b"], eps, True, groups)
+            h1 = self.gemm([(n1, cin, 9, h, w_, 0)], W[f"{name}.conv1.w"], cout, batch, h, w_, bias=W[f"{name}.conv1.b"], sbias=sb,
+                           gn_stats=G)                       # norm2 consumes h1 next
+            self.arena.free(n1)
+        # ---- norm2 + SiLU + conv2 (+ 1x1 shortcut over the raw inputs | + residual)
+        short = f"{name}.has_shortcut" in W
+        shapes2 = [(cout, 9)] + ([(ca, 1)] + ([(cb, 1)] if xb is not None else []) if short else [])
+        if self.fuses_groupnorm(shapes2, W[f"{name}.conv2.w"], cout, batch, h, w_, G, 1):
+            part, chunks = self.gn_statistics(h1, cout, None, 0, batch, hw, G)
+            srcs = [(h1, cout, 9, h, w_, 0)]
+            if short:
+                srcs += [(xa, ca, 1, h, w_, 0)] + ([(xb, cb, 1, h, w_, 0)] if xb is not None else [])
+            out = self.gemm(srcs, W[f"{name}.conv2.w"], cout, batch, h, w_, bias=W[f"{name}.conv2.b"], residual=None if short else xa,
+                            gn_stats=G if out_stats else 0, gn_in=(part, chunks, G, eps, W[f"{name}.gn2.g"], W[f"{name}.gn2.b"], True, 1))
+            self.arena.free(part)
+            self.arena.free(h1)
+            return out
+        n2 = self.groupnorm(h1, cout, None, 0, batch, hw, W[f"{name}.gn2.g"], W[f"{name}.gn2.b"], eps, True, groups)
         self.arena.free(h1)
-        if f"{name}.has_shortcut" in W:
+        if short:
             srcs = [(n2, cout, 9, h, w_, 0), (xa, ca, 1, h, w_, 0)]
             if xb is not None:
                 srcs.append((xb, cb, 1, h, w_, 0))
@@ -838,9 +903,16 @@ class HipEngine:
         hw = h * w_
         m = batch * hw
         G = self.ucfg.norm_num_groups
-        xn = self.groupnorm(x, c, None, 0, batch, hw, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
-        h0 = self.linear(xn, W[f"{n}.proj_in.w"], c, c, bias=W[f"{n}.proj_in.b"], row_stats=self.folds(xn, m, c, 3 * c))
-        self.arena.free(xn)
+        if self.fuses_groupnorm([(c, 1)], W[f"{n}.proj_in.w"], c, batch, h, w_, G, 1):
+            # Transformer2DModel.norm (no SiLU) inside proj_in
+            part, chunks = self.gn_statistics(x, c, None, 0, batch, hw, G)
+            h0 = self.gemm([(x, c, 1, h, w_, 0)], W[f"{n}.proj_in.w"], c, batch, h, w_, bias=W[f"{n}.proj_in.b"],
+                           row_stats=self.folds(x, m, c, 3 * c), gn_in=(part, chunks, G, 1e-6, W[f"{n}.norm.g"], W[f"{n}.norm.b"], False, 1))
+            self.arena.free(part)
+        else:
+            xn = self.groupnorm(x, c, None, 0, batch, hw, W[f"{n}.norm.g"], W[f"{n}.norm.b"], 1e-6, False)
+            h0 = self.linear(xn, W[f"{n}.proj_in.w"], c, c, bias=W[f"{n}.proj_in.b"], row_stats=self.folds(xn, m, c, 3 * c))
+            self.arena.free(xn)
         # self-attention
         qkv = self.ln_linear(h0, m, c, n, "ln1", "qkv", 3 * c)
         self._free_rs(h0)

@@ -128,6 +128,19 @@ typedef struct {
     int32_t w_groups;
     int32_t w_group_rows;
     int64_t w_group_stride;
+    /* GroupNorm(+SiLU) fused into the GEMM (north_star "conv3x3 + GroupNorm+SiLU fused"; diffusers ResnetBlock2D norm1+conv1,
+     * norm2+conv2(+conv_shortcut), Transformer2DModel norm+proj_in): the first gn_in_nsrc sources hold the RAW tensors; their channel
+     * concatenation is normalised with nn.GroupNorm(gn_in_groups, eps) from gn_in_partials (the statistics idb_groupnorm takes as
+     * partials_in: [batch][gn_in_chunks][gn_in_groups][2], gn_in_chunks <= 64), gamma / beta over those channels, then SiLU if
+     * gn_in_silu — by dedicated normalizer waves inside the kernel, bit-identical to idb_groupnorm followed by idb_gemm; zero padding
+     * stays zero.  Only plans that run one workgroup per CU take it (small grids: the batch-1 UNet): idb_gemm_fuses_groupnorm tells
+     * beforehand, idb_gemm returns IDB_EUNSUPPORTED otherwise and the caller runs idb_groupnorm + idb_gemm.  Needs stride 1, sources
+     * with the output's spatial grid, out_h*out_w a multiple or a divisor of the tile height.  NULL: off. */
+    const float* gn_in_partials;
+    int32_t gn_in_chunks, gn_in_groups, gn_in_nsrc, gn_in_silu;
+    float gn_in_eps;
+    const float* gn_in_gamma;
+    const float* gn_in_beta;
 } idb_gemm_desc;
 
 size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);
@@ -143,6 +156,8 @@ int32_t idb_gemm_row_stats_tiles(const idb_gemm_desc* d);
 int32_t idb_gemm_emits_gn_partials(const idb_gemm_desc* d, int32_t groups);
 /* 1 if the plan idb_gemm would run for `d` (bias / sample_bias NULL, one 1x1 source) can apply a folded LayerNorm (ln_*). */
 int32_t idb_gemm_folds_layernorm(const idb_gemm_desc* d);
+/* 1 if idb_gemm would run `d` with its fused GroupNorm (gn_in_* set) in ONE launch. */
+int32_t idb_gemm_fuses_groupnorm(const idb_gemm_desc* d);
 int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight packing (run once at load; SURVEY.md §8b "idb_pack_*"). src is fp32 in torch layout. */

@@ -670,3 +670,80 @@ def test_conv_256_row_loader_wave_tile_bit_identical_with_gn_partials(eng):
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
     assert getattr(out, "_gn", None) is not None and torch.allclose(ref._gn[0], out._gn[0], rtol=1e-5, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GroupNorm(+SiLU) applied by normalizer waves inside the conv (idb_gemm_desc.gn_in_*): the transform is gn_apply_kernel's
+# arithmetic on the same partial sums, so the result must equal idb_groupnorm(partials_in) + idb_gemm BIT FOR BIT
+# ---------------------------------------------------------------------------------------------------
+def _gn_ref_and_fused(eng, srcs_raw, c_norm, nsrc_norm, w, cout, b, h, w_, tile, silu, eps, seed, extra=None, split_k=0, **kw):
+    """srcs_raw: [(tensor [b,h,w,c], c, taps)]; the first nsrc_norm are normalised as one GroupNorm(32) over their concatenation."""
+    G = 32
+    gamma, beta = 1.0 + 0.3 * _rand((c_norm,), seed), 0.2 * _rand((c_norm,), seed + 1)
+    x0, c0 = srcs_raw[0][0], srcs_raw[0][1]
+    x1, c1 = (srcs_raw[1][0], srcs_raw[1][1]) if nsrc_norm == 2 else (None, 0)
+    part, chunks = eng.gn_statistics(x0, c0, x1, c1, b, h * w_, G)
+    # reference: the normalised tensor through HBM (idb_groupnorm with the SAME partials), then the plain GEMM
+    x0._gn = None
+    xn = eng.arena.alloc((b * h * w_, c_norm), eng.tdt)
+    from faceposegenerator_amd import _lib as L
+    L.check(eng.lib.idb_groupnorm(x0.data_ptr(), c0, None if x1 is None else x1.data_ptr(), c1, b, h * w_, G, eps, gamma.data_ptr(), beta.data_ptr(),
+                                  int(silu), xn.data_ptr(), eng.dt, eng._gn_ws.data_ptr(), eng._gn_ws.numel(), None, 0, part.data_ptr(), chunks, 0),
+            "idb_groupnorm")
+    taps0 = srcs_raw[0][2]
+    ref_srcs = [(xn, c_norm, taps0, h, w_, 0)] + [(t, c, tp, h, w_, 0) for (t, c, tp) in srcs_raw[nsrc_norm:]]
+    if nsrc_norm == 2:       # the fused form's K order is [src0 taps][src1 taps]: the reference GEMM needs the [tap][c0+c1] weight
+        wref = kw.pop("w_ref")
+    else:
+        wref = w
+    ref = eng.gemm(ref_srcs, wref, cout, b, h, w_, tile=tile - (tile // 10) * 10 + 10, split_k=split_k, **(extra or {}))
+    fused = eng.gemm([(t, c, tp, h, w_, 0) for (t, c, tp) in srcs_raw], w, cout, b, h, w_, tile=tile, split_k=split_k,
+                     gn_in=(part, chunks, G, eps, gamma, beta, silu, nsrc_norm), **(extra or {}))
+    torch.cuda.synchronize()
+    assert fused is not None, "the library declined the fused GroupNorm for this plan"
+    return ref, fused
+
+
+@pytest.mark.parametrize("b,h,cin,cout,tile,split_k", [(2, 16, 128, 320, 76, 1), (2, 32, 64, 128, 77, 1), (1, 16, 320, 320, 58, 2), (2, 8, 256, 256, 59, 4),
+                                                        (2, 8, 640, 128, 74, 1), (3, 16, 192, 160, 56, 1), (2, 8, 128, 160, 78, 1)])
+def test_fused_groupnorm_silu_conv3x3_bit_identical(eng, b, h, cin, cout, tile, split_k):
+    x = _rand((b, h, h, cin), 101, 1.5).to(eng.tdt)
+    w = eng.tile_weight(eng._pack_conv(_rand((cout, cin, 3, 3), 102, (9 * cin) ** -0.5)))
+    bias, sb = _rand((cout,), 103), _rand((b, cout), 104)
+    ref, fused = _gn_ref_and_fused(eng, [(x, cin, 9)], cin, 1, w, cout, b, h, h, tile, True, 1e-5, 105, extra=dict(bias=bias, sbias=(sb, 0, cout)),
+                                   split_k=split_k)
+    assert torch.equal(fused, ref)
+
+
+def test_fused_groupnorm_over_skip_concat_and_shortcut(eng):
+    """norm1 + conv1 over cat[x, skip] as two 3x3 sources (K order [src0 taps][src1 taps]) and norm2 + conv2 + 1x1 shortcut over the raw
+    inputs as three sources (only the first normalised)."""
+    b, h, ca, cb, cout = 2, 16, 128, 64, 160
+    xa, xb = _rand((b, h, h, ca), 111).to(eng.tdt), _rand((b, h, h, cb), 112, 2.0).to(eng.tdt)
+    wc = _rand((cout, ca + cb, 3, 3), 113, (9 * (ca + cb)) ** -0.5)
+    w_ref = eng.tile_weight(eng._pack_conv(wc))
+    w_split = eng.tile_weight(torch.cat([eng._pack_conv(wc[:, :ca].contiguous()), eng._pack_conv(wc[:, ca:].contiguous())], dim=1).contiguous())
+    bias = _rand((cout,), 114)
+    ref, fused = _gn_ref_and_fused(eng, [(xa, ca, 9), (xb, cb, 9)], ca + cb, 2, w_split, cout, b, h, h, 76, True, 1e-5, 115, extra=dict(bias=bias),
+                                   w_ref=w_ref)
+    assert torch.equal(fused, ref)
+    # conv2 + shortcut: [h1 (normalised) 3x3 | xa 1x1 | xb 1x1]
+    h1 = _rand((b, h, h, cout), 116, 1.3).to(eng.tdt)
+    w2 = eng.tile_weight(torch.cat([eng._pack_conv(_rand((cout, cout, 3, 3), 117, (9 * cout) ** -0.5)),
+                                    eng._pack_mat(_rand((cout, ca + cb), 118, (ca + cb) ** -0.5))], dim=1).contiguous())
+    ref, fused = _gn_ref_and_fused(eng, [(h1, cout, 9), (xa, ca, 1), (xb, cb, 1)], cout, 1, w2, cout, b, h, h, 76, True, 1e-5, 119,
+                                   extra=dict(bias=bias, gn_stats=32))
+    assert torch.equal(fused, ref)
+    assert getattr(fused, "_gn", None) is not None and torch.equal(fused._gn[0], ref._gn[0])
+
+
+def test_fused_groupnorm_proj_in_no_silu_with_row_stats(eng):
+    """Transformer2DModel.norm (eps 1e-6, no SiLU) inside proj_in (a 1x1 source), with the row statistics of a following folded LayerNorm."""
+    b, h, c = 2, 16, 320
+    x = _rand((b, h, h, c), 121, 2.0).to(eng.tdt)
+    w = eng.tile_weight(eng._pack_mat(_rand((c, c), 122, c ** -0.5)))
+    bias = _rand((c,), 123)
+    ref, fused = _gn_ref_and_fused(eng, [(x, c, 1)], c, 1, w, c, b, h, h, 56, False, 1e-6, 124, extra=dict(bias=bias, row_stats=True))
+    assert torch.equal(fused, ref)
+    if getattr(ref, "_rs", None) is not None:
+        assert getattr(fused, "_rs", None) is not None and torch.equal(fused._rs[0], ref._rs[0])

@@ -6,7 +6,7 @@ import torch
 from faceposegenerator_amd import spec as S
 from faceposegenerator_amd.engine import HipEngine
 be = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-eng = HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, "cuda:0", "bf16")
+eng = HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, "cuda:0", os.environ.get("IDB_DTYPE", "f16"))
 heads, n = 5, 4096
 c = heads * 64
 qkv = torch.randn(be * n, 3 * c, device=eng.device).to(eng.tdt)

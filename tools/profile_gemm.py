@@ -12,13 +12,14 @@ from faceposegenerator_amd.engine import HipEngine
 
 be = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+tile = int(sys.argv[3]) if len(sys.argv) > 3 else 0            # 0: the library's plan; e.g. 8 = 128x160 ring 2, 88 = 256x160 loader waves
 eng = HipEngine(S.TINY_UNET, S.TINY_VAE, None, None, "cuda:0", os.environ.get("IDB_DTYPE", "f16"))
 side, cin, cout = 64, 320, 320
 x = torch.randn(be * side * side, cin, device=eng.device).to(eng.tdt)
-w = (torch.randn(cout, 9 * cin, device=eng.device) * (9 * cin) ** -0.5).to(eng.tdt)
+w = eng.tile_weight((torch.randn(cout, 9 * cin, device=eng.device) * (9 * cin) ** -0.5).to(eng.tdt))
 for _ in range(n):
     eng.arena.reset()
-    eng.gemm([(x, cin, 9, side, side, 0)], w, cout, be, side, side)
+    eng.gemm([(x, cin, 9, side, side, 0)], w, cout, be, side, side, tile=tile)
 torch.cuda.synchronize()
 m = be * side * side
 print(f"conv3x3 {cin}->{cout} @{side}x{side} B_eff={be}: M={m} N={cout} K={9 * cin} flops/launch={2.0 * m * cout * 9 * cin:.4e} "
