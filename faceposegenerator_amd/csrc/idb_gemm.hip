@@ -723,15 +723,17 @@ __global__ __launch_bounds__(128 * WM + 256 + 64 * NV) void idb_gemm_kernel_gn(c
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pos = ((ks * 4 + fg) ^ (fr & 7)) * 16;
-            V8 af[MF], wf[NF];
+            // one weight fragment live at a time: with 4 MFMA waves the wave tile is 2x that of the 8-wave kernels and the workgroup's
+            // 16 waves cap a wave at 128 VGPRs (80 of them accumulators at 128x160)
+            V8 af[MF];
 #pragma unroll
             for (int i = 0; i < MF; ++i) af[i] = *(const V8*)(sA + i * 16 * 128 + pos);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) wf[j] = *(const V8*)(sB + j * 16 * 128 + pos);
+            for (int j = 0; j < NF; ++j) {
+                const V8 wf = *(const V8*)(sB + j * 16 * 128 + pos);
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
+                for (int i = 0; i < MF; ++i) acc[i][j] = Op<T>::mfma16(wf, af[i], acc[i][j]);
+            }
         }
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
@@ -1420,7 +1422,7 @@ static size_t gn_fused_lds(int bm, int stage_rows, int ns, const GemmParams& p) 
 
 template <typename T, int MF, int NF, int NS, int WM>
 int launch_tile_gn(const GemmParams& p, const Plan& pl, hipStream_t st) {
-    constexpr int NV = 4, LR = 32, NJ = (32 * NF + LR - 1) / LR, BM = 16 * MF * WM;
+    constexpr int NV = 8, LR = 32, NJ = (32 * NF + LR - 1) / LR, BM = 16 * MF * WM;
     const size_t lds = gn_fused_lds(BM, BM + NJ * LR, NS, p);
     if (lds > 160 * 1024) {
         idb_set_error("idb_gemm: fused GroupNorm needs %zu bytes of LDS for this tile", lds);
@@ -1444,12 +1446,16 @@ int launch_tile_gn(const GemmParams& p, const Plan& pl, hipStream_t st) {
 
 template <typename T>
 int launch_gn_by_tile(const GemmParams& p, const Plan& pl, hipStream_t st) {
-    switch (pl.tile % 10) {       // 64-row tiles: 4-stage ring; 128-row tiles: 3 stages (LDS)
-        case 4: return launch_tile_gn<T, 1, 2, 4, 4>(p, pl, st);
-        case 6: return launch_tile_gn<T, 1, 5, 4, 4>(p, pl, st);
-        case 7: return launch_tile_gn<T, 1, 4, 4, 4>(p, pl, st);
-        case 8: return launch_tile_gn<T, 2, 5, 3, 4>(p, pl, st);
-        default: return launch_tile_gn<T, 2, 4, 3, 4>(p, pl, st);
+    // 4 MFMA waves (2 x 2, one per SIMD: the wave tile is twice that of the 8-wave kernels of the same workgroup tile) + 4 loader waves +
+    // 8 normalizer waves = 16 waves: with 4 normalizer waves the transform (9x redundant for a 3x3 conv: every tap re-reads its pixels)
+    // was the K-step's critical path — 50 vs 34 us on conv 320->320 @64x64 at B_eff 2.  64-row tiles: 4-stage ring; 128-row: 3 (LDS)
+    switch (pl.tile % 10) {
+        case 4: return launch_tile_gn<T, 2, 2, 4, 2>(p, pl, st);
+        case 6: return launch_tile_gn<T, 2, 5, 4, 2>(p, pl, st);
+        case 7: return launch_tile_gn<T, 2, 4, 4, 2>(p, pl, st);
+        default:       // 128-row tiles: a 4-wave MFMA role needs > 128 VGPRs there (16 waves per workgroup): not instantiated, gemm_fuses_gn says no
+            idb_set_error("idb_gemm: fused GroupNorm is built for 64-row tiles only");
+            return IDB_EUNSUPPORTED;
     }
 }
 
@@ -1582,7 +1588,8 @@ static bool gemm_folds_ln(const idb_gemm_desc* d, const Plan& pl) {
 static bool gemm_epilogue_emits_gn(const idb_gemm_desc* d, const Plan& pl, int groups) {
     if ((pl.tile / 10 > 2 && pl.tile / 10 < 5) || d->geglu || !gemm_uses_lds_epilogue(d, pl)) return false;
     const TileCfg& t = kTiles[pl.tile % 10];
-    return idb_epilogue_emits_gn(16 * t.mf * t.wm * (pl.tile / 10 == 8 ? 2 : 1), 32 * t.nf, 128 * t.wm, pl.M, d->n, groups) && (long long)d->out_h * d->out_w % 64 == 0 &&
+    const int epi_threads = d->gn_in_partials ? 256 : 128 * t.wm;      // the fused-GroupNorm kernel has 4 MFMA waves
+    return idb_epilogue_emits_gn(16 * t.mf * t.wm * (pl.tile / 10 == 8 ? 2 : 1), 32 * t.nf, epi_threads, pl.M, d->n, groups) && (long long)d->out_h * d->out_w % 64 == 0 &&
            d->out_ld == d->n;
 }
 
@@ -1599,6 +1606,7 @@ static bool gemm_fuses_gn(const idb_gemm_desc* d, const Plan& pl) {
     if (!d->gn_in_partials) return false;
     if (pl.tile / 10 < 5 || pl.tile / 10 > 7 || d->stride != 1 || d->ln_stats || d->geglu || d->gn_in_nsrc < 1 || d->gn_in_nsrc > d->nsrc) return false;
     const int bm = 16 * kTiles[pl.tile % 10].mf * kTiles[pl.tile % 10].wm;
+    if (bm != 64) return false;                        // 64x160 / 64x128 / 64x64 plans (launch_gn_by_tile)
     const long long hw = (long long)d->out_h * d->out_w;
     if (!(hw % bm == 0 || (bm % hw == 0 && bm / hw <= 2))) return false;
     long long cn = 0;

@@ -129,6 +129,12 @@ class HipEngine:
         # GroupNorm(+SiLU) applied by normalizer waves inside the consuming conv / proj_in (idb_gemm_desc.gn_in_*) wherever the plan is a
         # one-workgroup-per-CU loader-wave plan (the batch-1 UNet); IDB_GN_CONV=0: idb_groupnorm + idb_gemm everywhere
         self._gn_conv = os.environ.get("IDB_GN_CONV", "1") != "0" and dtype != "fp8"
+        # measured per shape at B_eff 2 (tools/bench_gnfuse.py, profiles/r03): Transformer2DModel.norm + proj_in at the 64x64 level 17.9 ->
+        # 13.3 us (no SiLU, 5 K-steps, 320-channel table); every 3x3 conv LOSES (34 -> 44 us on conv 320->320: with 4 MFMA waves per
+        # workgroup the fragment reads are no longer hidden, and every tap re-normalises its pixels), deeper proj_in lose to the table
+        # prologue.  So the resnet convs keep idb_groupnorm + idb_gemm unless IDB_GN_CONV_RESNET=1, proj_in fuses up to 320 channels
+        self._gn_conv_resnet = os.environ.get("IDB_GN_CONV_RESNET", "0") == "1"
+        self._gn_conv_max_c = int(os.environ.get("IDB_GN_CONV_MAX_C", "320"))
         self._gn_conv_cache: Dict[tuple, bool] = {}
         # weights in the K-tiled 16-row-block layout (idb_tile_weight): a workgroup's K loop reads each of its row blocks as one
         # contiguous stream instead of 128-byte pieces at a K*2-byte stride; IDB_W_TILED=0 keeps [n][K] rows
@@ -860,7 +866,7 @@ class HipEngine:
         # ---- norm1 + SiLU + conv1: inside the conv (normalizer waves) where the plan allows, else idb_groupnorm + idb_gemm
         w1 = W.get(f"{name}.conv1.wsplit") if xb is not None else W[f"{name}.conv1.w"]
         shapes1 = [(ca, 9)] + ([(cb, 9)] if xb is not None else [])
-        if w1 is not None and self.fuses_groupnorm(shapes1, w1, cout, batch, h, w_, G, len(shapes1)):
+        if w1 is not None and self._gn_conv_resnet and self.fuses_groupnorm(shapes1, w1, cout, batch, h, w_, G, len(shapes1)):
             part, chunks = self.gn_statistics(xa, ca, xb, cb, batch, hw, G)
             srcs1 = [(xa, ca, 9, h, w_, 0)] + ([(xb, cb, 9, h, w_, 0)] if xb is not None else [])
             h1 = self.gemm(srcs1, w1, cout, batch, h, w_, bias=W[f"{name}.conv1.b"], sbias=sb, gn_stats=G,
@@ -874,7 +880,7 @@ class HipEngine:
         # ---- norm2 + SiLU + conv2 (+ 1x1 shortcut over the raw inputs | + residual)
         short = f"{name}.has_shortcut" in W
         shapes2 = [(cout, 9)] + ([(ca, 1)] + ([(cb, 1)] if xb is not None else []) if short else [])
-        if self.fuses_groupnorm(shapes2, W[f"{name}.conv2.w"], cout, batch, h, w_, G, 1):
+        if self._gn_conv_resnet and self.fuses_groupnorm(shapes2, W[f"{name}.conv2.w"], cout, batch, h, w_, G, 1):
             part, chunks = self.gn_statistics(h1, cout, None, 0, batch, hw, G)
             srcs = [(h1, cout, 9, h, w_, 0)]
             if short:
@@ -903,7 +909,7 @@ class HipEngine:
         hw = h * w_
         m = batch * hw
         G = self.ucfg.norm_num_groups
-        if self.fuses_groupnorm([(c, 1)], W[f"{n}.proj_in.w"], c, batch, h, w_, G, 1):
+        if c <= self._gn_conv_max_c and self.fuses_groupnorm([(c, 1)], W[f"{n}.proj_in.w"], c, batch, h, w_, G, 1):
             # Transformer2DModel.norm (no SiLU) inside proj_in
             part, chunks = self.gn_statistics(x, c, None, 0, batch, hw, G)
             h0 = self.gemm([(x, c, 1, h, w_, 0)], W[f"{n}.proj_in.w"], c, batch, h, w_, bias=W[f"{n}.proj_in.b"],

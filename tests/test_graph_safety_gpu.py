@@ -39,7 +39,7 @@ def test_multistep_graph_replay_touches_no_freed_memory(lib):
     torch.cuda.synchronize()
     assert _intact(sent, 0xA5), "graph replay wrote into memory it no longer owns"
     assert torch.equal(first, again)
-    ent = next(v for k, v in pipe._engine()._graphs.items() if k[-1] is True)
+    ent = next(v for k, v in pipe._engine()._graphs.items() if k[-2] is True)     # key: (..., multistep, lora groups)
     assert ent["hist"] is not None
 
 
