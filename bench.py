@@ -39,14 +39,14 @@ _TILE_SHAPES = {1: "128x160", 2: "128x128", 3: "64x160", 4: "64x64,8w", 5: "128x
 _TILE_VARIANTS = {0: "idb_gemm_kernel<{},ring2>", 1: "idb_gemm_kernel<{},ring3>", 2: "idb_gemm_kernel<{},ring4>",
                   3: "idb_gemm_kernel_rs<{}>", 4: "idb_gemm_kernel_pl<{}>", 5: "idb_gemm_kernel_lw<{},4 loader waves,ring3>",
                   6: "idb_gemm_kernel_lw<{},8 loader waves,ring3>", 7: "idb_gemm_kernel_lw<{},4 loader waves,ring4>",
-                  8: "idb_gemm_kernel_lw<{},4 loader waves,ring3>"}
+                  8: "idb_gemm_kernel_lw<{},4 loader waves,ring3>", 9: "idb_conv_patch_kernel<{},halo patch resident,2+2 loader waves>"}
 
 
 class _TileNames(dict):
     """idb_gemm_plan tile id -> kernel instance name (id = shape + 10 * variant, see idb_gemm.hip)."""
     def __missing__(self, t):
         shape = _TILE_SHAPES[t % 10]
-        if t // 10 == 8:                                   # the 256-row loader-wave tiles
+        if t // 10 >= 8:                                   # the 256-row loader-wave tiles
             shape = shape.replace("128x", "256x", 1)
         return _TILE_VARIANTS[t // 10].format(shape)
 
@@ -234,6 +234,8 @@ def mangled_gemm_name(tile: int, dtype: str) -> str:
         return f"idb_gemm_kernel_rsI{t}Li{mf}ELi{nf}EE"
     if v == 4:
         return f"idb_gemm_kernel_plI{t}Li{mf}ELi{nf}EE"
+    if v == 9:                                             # idb_conv_patch_kernel<T, NF>
+        return f"idb_conv_patch_kernelI{t}Li{nf}EE"
     if v >= 5:                                             # idb_gemm_kernel_lw<T, MF, NF, NS, WM, LW>
         ns, lw = {5: (3, 4), 6: (3, 8), 7: (4, 4), 8: (3, 4)}[v]
         return f"idb_gemm_kernel_lwI{t}Li{mf * (2 if v == 8 else 1)}ELi{nf}ELi{ns}ELi{wm}ELi{lw}EE"

@@ -395,28 +395,335 @@ __global__ __launch_bounds__(128 * WM + 64 * LW) void idb_gemm_kernel_lw(const G
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float2 ln_part = make_float2(0.f, 0.f);
     if (p.ln_stats) ln_part = idb_ln_row_partials<BM, CT>(p, m0, tid);
-    int cur = 0;
-    for (int it = 0; it < nk; ++it) {
-        // lgkmcnt(0): this wave's fragment reads of the previous stage have returned before the loaders may overwrite its buffer
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
-        const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int pos = ((ks * 4 + fg) ^ (fr & 7)) * 16;
-            V8 af[MF], wf[NF];
-#pragma unroll
-            for (int i = 0; i < MF; ++i) af[i] = *(const V8*)(sA + i * 16 * 128 + pos);
-#pragma unroll
-            for (int j = 0; j < NF; ++j) wf[j] = *(const V8*)(sB + j * 16 * 128 + pos);
-#pragma unroll
+    if constexpr (MF >= 2) {
+        // The K-step is rotated by half a step around the barrier: the fragments of the stage's SECOND 32-deep half are read before the
+        // barrier that publishes the next stage and multiplied after it, while the next stage's first half is being read — every wave
+        // leaves a barrier with 4*MF*NF/4 MFMAs of operands already in registers instead of with an LDS round trip in front of its
+        // first MFMA (all waves of the workgroup pass the barrier together, so that round trip was exposed once per K-step).  The
+        // protocol with the loaders is unchanged (barrier `it` publishes stage `it` and proves stage `it - 1` read: its reads are
+        // drained by lgkmcnt(0) in front of the barrier) and so is the accumulation order: results stay bit-identical.
+        const int pos0 = (fg ^ (fr & 7)) * 16, pos1 = pos0 ^ 64;
+        const char* sA0 = smem + (wm * 16 * MF + fr) * 128;
+        const char* sB0 = smem + BM * 128 + (wn * 16 * NF + fr) * 128;
+        V8 af0[MF], wf0[NF], af1[MF], wf1[NF];
+        asm volatile("s_barrier" ::: "memory");
+    #pragma unroll
+        for (int i = 0; i < MF; ++i) af0[i] = *(const V8*)(sA0 + i * 16 * 128 + pos0);
+    #pragma unroll
+        for (int j = 0; j < NF; ++j) wf0[j] = *(const V8*)(sB0 + j * 16 * 128 + pos0);
+        int cur = 0;
+        for (int it = 0; it + 1 < nk; ++it) {
+            const char* sA = sA0 + cur * STAGE;
+            const char* sB = sB0 + cur * STAGE;
+    #pragma unroll
+            for (int i = 0; i < MF; ++i) af1[i] = *(const V8*)(sA + i * 16 * 128 + pos1);
+    #pragma unroll
+            for (int j = 0; j < NF; ++j) wf1[j] = *(const V8*)(sB + j * 16 * 128 + pos1);
+    #pragma unroll
             for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
+    #pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf0[j], af0[i], acc[i][j]);
+            cur = cur + 1 == NS ? 0 : cur + 1;
+            // lgkmcnt(0): this wave's fragment reads of stage `it` have returned before the loaders may overwrite its buffer.  As a
+            // BUILTIN (0xC07F = lgkmcnt 0, vmcnt / expcnt untouched): the compiler's wait-count pass cannot see inside inline asm and
+            // would otherwise make the first MFMAs behind the barrier wait for the reads issued behind it as well
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            asm volatile("s_barrier" ::: "memory");
+            const char* nA = sA0 + cur * STAGE;
+            const char* nB = sB0 + cur * STAGE;
+    #pragma unroll
+            for (int i = 0; i < MF; ++i) af0[i] = *(const V8*)(nA + i * 16 * 128 + pos0);
+    #pragma unroll
+            for (int j = 0; j < NF; ++j) wf0[j] = *(const V8*)(nB + j * 16 * 128 + pos0);
+    #pragma unroll
+            for (int i = 0; i < MF; ++i)
+    #pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf1[j], af1[i], acc[i][j]);
         }
-        cur = cur + 1 == NS ? 0 : cur + 1;
+        {                                                          // the last K-step: no barrier behind its first half
+            const char* sA = sA0 + cur * STAGE;
+            const char* sB = sB0 + cur * STAGE;
+    #pragma unroll
+            for (int i = 0; i < MF; ++i) af1[i] = *(const V8*)(sA + i * 16 * 128 + pos1);
+    #pragma unroll
+            for (int j = 0; j < NF; ++j) wf1[j] = *(const V8*)(sB + j * 16 * 128 + pos1);
+    #pragma unroll
+            for (int i = 0; i < MF; ++i)
+    #pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf0[j], af0[i], acc[i][j]);
+    #pragma unroll
+            for (int i = 0; i < MF; ++i)
+    #pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf1[j], af1[i], acc[i][j]);
+        }
+    } else {
+        // 64-row tiles (the short-K linears of the batch-1 UNet): plain order — barrier, both halves' reads, MFMAs (the rotated loop was
+        // measured -0.3 % end to end at batch 1 with these tiles in it: nothing to hide behind 5-10 MFMAs per half)
+        int cur = 0;
+        for (int it = 0; it < nk; ++it) {
+            // lgkmcnt(0): this wave's fragment reads of the previous stage have returned before the loaders may overwrite its buffer
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const char* sA = smem + cur * STAGE + (wm * 16 * MF + fr) * 128;
+            const char* sB = smem + cur * STAGE + BM * 128 + (wn * 16 * NF + fr) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int pos = ((ks * 4 + fg) ^ (fr & 7)) * 16;
+                V8 af[MF], wf[NF];
+#pragma unroll
+                for (int i = 0; i < MF; ++i) af[i] = *(const V8*)(sA + i * 16 * 128 + pos);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) wf[j] = *(const V8*)(sB + j * 16 * 128 + pos);
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf[j], af[i], acc[i][j]);
+            }
+            cur = cur + 1 == NS ? 0 : cur + 1;
+        }
     }
     idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, kz, p.ln_stats != nullptr, ln_part);
+#endif
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Patch-resident 3x3 conv (round 3) for large grids: the 256-row loader-wave tile with the ACTIVATION operand fetched once per
+// 64-channel chunk instead of once per tap.  A tile of 256 output pixels is whole image rows (W | 256), so for one channel chunk
+// the nine taps read shifted windows of ONE halo patch — (rows + 2) x (W + 2) pixels x 128 B, <= 400 pixels = 50 KB — that sits in
+// LDS while the K loop walks tap after tap over it: K order is chunk-major ([chunk][tap], the weight K-step index is
+// tap * C/64 + chunk, an SGPR offset either way).  Per K-step the workgroup now moves patch/9 + BN*128 B into LDS instead of
+// (256 + BN) * 128 B: 26 KB instead of 52 KB at BN = 160 — 195 instead of 97 FLOP per byte moved L2 -> LDS, and
+// the same drop in LDS write traffic, which shares the LDS port with the fragment reads.
+//   roles (wave index): [0, 8) MFMA — fragment mapping, epilogue and wave tile of idb_gemm_kernel_lw<T,4,NF,3,4,4>; [8, 10) weight
+//   loaders (3-stage ring, counted vmcnt); [10, 12) patch loaders (double-buffered patch: chunk c+1 lands while the nine taps of
+//   chunk c run; one vmcnt(0) per chunk).  ONE s_barrier per K-step for every role, no flags, no polling.
+//   1x1 K segments (a ResnetBlock2D's conv_shortcut fused behind conv2) go through the same structure with a halo-less "patch" of the
+//   256 tile pixels and one tap per chunk.  Zero padding = out-of-range buffer offsets, as everywhere.
+// The accumulation order over K differs from the tap-major kernels, so results are equal to rounding, not bit-identical.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int NF>
+__global__ __launch_bounds__(768) void idb_conv_patch_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using V8 = typename Op<T>::v8;
+    constexpr int MF = 4, WM = 4, NS = 3;
+    constexpr int BM = 256, BN = 32 * NF;
+    constexpr int PATCH = 400 * 128;                           // bytes of one patch buffer (<= 400 pixels, host check)
+    constexpr int NPI = 25;                                    // 1 KB wave-instructions per patch-loader wave (400 px / 2 waves / 8)
+    constexpr int NJ = BN / 16;                                // weight-row sweeps of the two weight loaders (8 rows per instruction)
+    constexpr int BSTAGE = BN * 128;
+    static_assert(2 * PATCH + NS * BSTAGE <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem + 2 * PATCH;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wg;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    }
+    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = p.ktiles;
+    // tile geometry: R image rows of width W; nimg whole images when the image is smaller than the tile
+    const int W = p.OW, H = p.HW / W;
+    const int nimg = p.HW >= BM ? 1 : BM / p.HW;
+    const int RI = BM / W / nimg;                              // tile rows per image
+
+    if (wave >= 10) {
+        // ---------------- patch loaders ----------------
+        const int pw = wave - 10;
+        const int q8 = lane >> 3;
+        const int b0 = m0 / p.HW, y0 = (m0 - b0 * p.HW) / W;
+        unsigned voff[NPI];
+        int seg = -1, npi = 0;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src[0].ptr, 0, p.src[0].bytes, IDB_RSRC_FLAGS);
+        auto setup = [&](int s) {
+            const GemmSrcK S = p.src[s];
+            rs = __builtin_amdgcn_make_buffer_rsrc((void*)S.ptr, 0, S.bytes, IDB_RSRC_FLAGS);
+            const int h = S.taps == 9 ? 1 : 0;
+            const int PW = W + 2 * h, RIh = RI + 2 * h;
+            const int PP = nimg * RIh * PW;
+            npi = (PP + 15) >> 4;
+#pragma unroll
+            for (int i = 0; i < NPI; ++i) {
+                const int q = (i * 2 + pw) * 8 + q8;
+                const int pr = q / PW, px = q - pr * PW;
+                const int img = pr / RIh, lr = pr - img * RIh;
+                const int y = y0 + lr - h, x = px - h;
+                const bool ok = q < PP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                const int pix = ((b0 + img) * H + y) * W + x;
+                voff[i] = ok ? (unsigned)pix * (unsigned)(S.C * 2) + (unsigned)(((lane & 7) ^ q8) * 16) : IDB_OOB;
+            }
+            seg = s;
+        };
+        auto issue = [&](int s, int c, int buf) {
+            if (s != seg) setup(s);
+            char* dst = smem + buf * PATCH + pw * 1024;
+            const unsigned soff = (unsigned)c * 128u;
+#pragma unroll
+            for (int i = 0; i < NPI; ++i)
+                if (i < npi) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst + i * 2048), 16, voff[i], soff, 0, 0);
+        };
+        int s = 0, c = 0, buf = 0, done = 0;
+        issue(0, 0, 0);
+        while (done < nk) {
+            const int taps = p.src[s].taps, CS = p.src[s].C >> 6;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // first tap of this chunk: its patch has landed
+            done += taps;
+            int s2 = s, c2 = c + 1;
+            if (c2 == CS) { c2 = 0; ++s2; }
+            if (done < nk) issue(s2, c2, buf ^ 1);             // into the buffer of the PREVIOUS chunk: every read of it is behind the barrier
+            for (int t = 1; t < taps; ++t) asm volatile("s_barrier" ::: "memory");
+            s = s2; c = c2; buf ^= 1;
+        }
+        return;
+    }
+    if (wave >= 8) {
+        // ---------------- weight loaders ----------------
+        const int bw = wave - 8;
+        const int lrow = lane >> 3;
+        const unsigned cg16 = ((lane & 7) ^ lrow) * 16;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + idb_weight_group(p, m0) * p.w_group_stride), 0, p.w_bytes, IDB_RSRC_FLAGS);
+        unsigned w_voff[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + j * 16 + bw * 8 + lrow;
+            w_voff[j] = n < p.N ? (unsigned)(n >> 4) * p.w_blk_bytes + (unsigned)(n & 15) * p.w_row_bytes + cg16 : IDB_OOB;
+        }
+        int s = 0, c = 0, tap = 0, base = 0;
+        int taps = p.src[0].taps, CS = p.src[0].C >> 6;
+        auto stage = [&](int buf) {
+            char* sB = ring + buf * BSTAGE + bw * 1024;
+            const unsigned soff = (unsigned)(base + tap * CS + c) * p.w_kstep;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sB + j * 2048), 16, w_voff[j], soff, 0, 0);
+            if (++tap == taps) {
+                tap = 0;
+                if (++c == CS) {
+                    c = 0;
+                    base += taps * CS;
+                    if (s < IDB_MAX_SRC - 1) ++s;
+                    taps = p.src[s].taps;
+                    CS = p.src[s].C >> 6;
+                }
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st)
+            if (st < nk) stage(st);
+        int cur = 0;
+        for (int it = 0; it < nk; ++it) {
+            if (it + NS - 2 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * NJ) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (it + NS - 1 < nk) stage(cur == 0 ? NS - 1 : cur - 1);
+            cur = cur + 1 == NS ? 0 : cur + 1;
+        }
+        return;
+    }
+
+    // ---------------- MFMA waves ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int rr[MF], xx[MF];                                        // tile row -> (patch row without halo, x)
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int ml = wm * 64 + i * 16 + fr;
+        const int r = ml / W;
+        xx[i] = ml - r * W;
+        rr[i] = r + 2 * (r / RI);                              // + 2 halo rows per image in front (9-tap segments only)
+    }
+    // K-step state (segment s, chunk c, tap t) and the half-step rotation around the barrier of idb_gemm_kernel_lw: the second 32-deep
+    // half of a K-step is read before the barrier that publishes the next one and multiplied behind it
+    int cur = 0, pb = 0, s = 0, c = 0, t = 0, ky = 0, kx = 0;
+    int taps = p.src[0].taps, CS = p.src[0].C >> 6, h = taps == 9 ? 1 : 0, PW = W + 2 * h;
+    int pp0[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) pp0[i] = h ? rr[i] * PW + xx[i] : wm * 64 + i * 16 + fr;
+    const int posw0 = (fg ^ (fr & 7)) * 16;
+    const char* sBw = ring + (wn * 16 * NF + fr) * 128;
+    unsigned a_addr[MF];
+    auto addr = [&]() {
+        const int toff = ky * PW + kx;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int pp = pp0[i] + toff;
+            a_addr[i] = (unsigned)(pb * PATCH) + (unsigned)pp * 128u + (unsigned)((fg ^ (pp & 7)) << 4);
+        }
+    };
+    auto advance = [&]() {
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        if (++kx == 3) { kx = 0; ++ky; }
+        if (++t == taps) {
+            t = 0; ky = 0; kx = 0;
+            pb ^= 1;
+            if (++c == CS) {
+                c = 0;
+                if (s < IDB_MAX_SRC - 1) ++s;
+                taps = p.src[s].taps;
+                CS = p.src[s].C >> 6;
+                h = taps == 9 ? 1 : 0;
+                PW = W + 2 * h;
+#pragma unroll
+                for (int i = 0; i < MF; ++i) pp0[i] = h ? rr[i] * PW + xx[i] : wm * 64 + i * 16 + fr;
+            }
+        }
+    };
+    V8 af0[MF], wf0[NF], af1[MF], wf1[NF];
+    asm volatile("s_barrier" ::: "memory");
+    addr();
+#pragma unroll
+    for (int i = 0; i < MF; ++i) af0[i] = *(const V8*)(smem + a_addr[i]);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) wf0[j] = *(const V8*)(sBw + j * 16 * 128 + posw0);
+    for (int it = 0; it + 1 < nk; ++it) {
+        const char* sB = sBw + cur * BSTAGE;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af1[i] = *(const V8*)(smem + (a_addr[i] ^ 64u));
+#pragma unroll
+        for (int j = 0; j < NF; ++j) wf1[j] = *(const V8*)(sB + j * 16 * 128 + (posw0 ^ 64));
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf0[j], af0[i], acc[i][j]);
+        advance();
+        addr();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0), as a builtin (see idb_gemm_kernel_lw)
+        asm volatile("s_barrier" ::: "memory");
+        const char* nB = sBw + cur * BSTAGE;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af0[i] = *(const V8*)(smem + a_addr[i]);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) wf0[j] = *(const V8*)(nB + j * 16 * 128 + posw0);
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf1[j], af1[i], acc[i][j]);
+    }
+    {
+        const char* sB = sBw + cur * BSTAGE;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af1[i] = *(const V8*)(smem + (a_addr[i] ^ 64u));
+#pragma unroll
+        for (int j = 0; j < NF; ++j) wf1[j] = *(const V8*)(sB + j * 16 * 128 + (posw0 ^ 64));
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf0[j], af0[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf1[j], af1[i], acc[i][j]);
+    }
+    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, 0, false, make_float2(0.f, 0.f));
 #endif
 }
 
@@ -1170,6 +1477,21 @@ struct Plan {
     long long K;
 };
 
+// idb_conv_patch_kernel's shapes: whole tiles of 256 output pixels that are whole image rows (or whole images), every K segment on the
+// output grid; the halo patch of one tile is at most 400 pixels
+static bool conv_patch_ok(const idb_gemm_desc* d, long long M) {
+    if (d->stride != 1 || d->pad_mode == 1 || d->geglu || d->ln_stats || d->gn_in_partials || d->split_k > 1 || d->nsrc < 1 || d->src[0].taps != 9) return false;
+    const int W = d->out_w, H = d->out_h;
+    if (!(W == 8 || W == 16 || W == 32 || W == 64) || M % 256) return false;
+    const long long HW = (long long)H * W;
+    if (!(HW % 256 == 0 || 256 % HW == 0)) return false;
+    const int nimg = HW >= 256 ? 1 : (int)(256 / HW);
+    if (nimg * (256 / W / nimg + 2) * (W + 2) > 400) return false;
+    for (int s = 0; s < d->nsrc; ++s)
+        if (d->src[s].upsample || d->src[s].in_h != H || d->src[s].in_w != W || d->src[s].channels % 64) return false;
+    return true;
+}
+
 int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     IDB_REQUIRE(d != nullptr, "idb_gemm: null descriptor");
     IDB_REQUIRE(idb_is_operand_dtype(d->dtype), "idb_gemm: dtype must be bf16 or f16 (got %d)", d->dtype);
@@ -1229,9 +1551,9 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     // 8 -> loader-wave variant with TWICE the rows (shapes 8 / 9 only: 256x160 / 256x128, 8 MFMA waves + 4 loader waves, 3-stage ring, one
     //      workgroup per CU with all 160 KB of LDS): 97 / 85 FLOP per byte moved L2 -> LDS instead of 73 for large grids
     const bool lw_tile = tile == 4 || (tile >= 6 && tile <= 9);
-    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 8 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
+    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 9 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
                     !(ring3 == 4 && tile > 2) && !(ring3 > 1 && ring3 < 5 && (tile >= 6 || tile == 4)) && !(ring3 >= 5 && !lw_tile) &&
-                    !(ring3 == 8 && tile < 8),
+                    !(ring3 >= 8 && tile < 8),
                 "idb_gemm: tile id out of range");
     const bool plain = d->nsrc == 1 && d->src[0].taps == 1 && d->src[0].in_h == 1 && d->src[0].in_w == 1;
     const bool pl_ok = plain && d->split_k <= 1 && d->out_dtype == d->dtype && (d->geglu ? d->n / 2 : d->n) % 4 == 0 &&
@@ -1322,9 +1644,17 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         static const int env_big = [] { const char* e = getenv("IDB_GEMM_BIG_TILES"); return e ? atoi(e) : 512; }();
         const long long blocks256 = ((M + 255) / 256) * ((d->n + 32 * kTiles[tile].nf - 1) / (32 * kTiles[tile].nf));
         if (env_big > 0 && blocks256 >= env_big) ring3 = 8;
+        // 3x3 stride-1 convs on that plan: the patch-resident form (idb_conv_patch_kernel).  IDB_CONV_PATCH=0: tap-major 256-row tiles
+        static const int env_patch = [] { const char* e = getenv("IDB_CONV_PATCH"); return e ? atoi(e) : 1; }();
+        if (ring3 == 8 && env_patch && conv_patch_ok(d, M)) ring3 = 9;
+    }
+    if (ring3 == 9 && !conv_patch_ok(d, M)) {
+        idb_set_error("idb_gemm: tile %d (patch-resident conv) needs a 3x3 stride-1 pad-1 first source, 1x1 / 3x3 sources on the output grid without "
+                      "upsampling, out_w in {8,16,32,64}, whole tiles of 256 pixels, no folded LayerNorm / fused GroupNorm / GEGLU / split-K", d->tile);
+        return IDB_EUNSUPPORTED;
     }
     pl->tile = tile + 10 * ring3;
-    const int bm = 16 * kTiles[tile].mf * kTiles[tile].wm * (ring3 == 8 ? 2 : 1), bn = 32 * kTiles[tile].nf;
+    const int bm = 16 * kTiles[tile].mf * kTiles[tile].wm * (ring3 >= 8 ? 2 : 1), bn = 32 * kTiles[tile].nf;
     pl->tiles_m = (int)((M + bm - 1) / bm);
     pl->tiles_n = (d->n + bn - 1) / bn;
     const long long blocks = (long long)pl->tiles_m * pl->tiles_n;
@@ -1332,7 +1662,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     int sk = d->split_k;
     if (sk <= 0) {
         sk = 1;
-        const bool small_tile = kTiles[tile].mf * kTiles[tile].wm <= 4 && ring3 != 8;     // 64-row tiles
+        const bool small_tile = kTiles[tile].mf * kTiles[tile].wm <= 4 && ring3 < 8;     // 64-row tiles
         if (auto_sk) {
             sk = auto_sk;
         } else if (!d->geglu && small_tile && blocks < 96 && pl->ktiles >= 10) {
@@ -1351,7 +1681,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
             if (sk < 1) sk = 1;
         }
     }
-    if (pl->tile / 10 == 4) sk = 1;
+    if (pl->tile / 10 == 4 || pl->tile / 10 == 9) sk = 1;
     IDB_REQUIRE(!(d->geglu && sk > 1), "idb_gemm: GEGLU does not support split-K");
     if (d->act) sk = 1;
     if (sk > pl->ktiles) sk = pl->ktiles;
@@ -1411,6 +1741,24 @@ int launch_tile_lw(const GemmParams& p, const Plan& pl, hipStream_t st) {
     dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.splitk);
     hipLaunchKernelGGL((idb_gemm_kernel_lw<T, MF, NF, NS, WM, LW>), grid, dim3(128 * WM + 64 * LW), LDS, st, p);
     IDB_CHECK_LAUNCH("idb_gemm(lw)");
+    return IDB_OK;
+}
+
+template <typename T, int NF>
+int launch_conv_patch(const GemmParams& p, const Plan& pl, hipStream_t st) {
+    constexpr int LDS = 2 * 400 * 128 + 3 * 32 * NF * 128;
+    static_assert(LDS <= 160 * 1024, "patch buffers + weight ring do not fit");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_conv_patch_kernel<T, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            idb_set_error("idb_gemm: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
+            return IDB_EHIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((idb_conv_patch_kernel<T, NF>), dim3(pl.tiles_m * pl.tiles_n), dim3(768), LDS, st, p);
+    IDB_CHECK_LAUNCH("idb_gemm(patch)");
     return IDB_OK;
 }
 
@@ -1517,7 +1865,9 @@ int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
         return idb_finish_splitk<T>(p, pl.M, d->n, d->batch, pl.splitk, d->gn_partials, d->gn_groups, d->dtype, st);
     }
     if (pl.tile / 10 >= 5) {
-        if (pl.tile / 10 == 8)
+        if (pl.tile / 10 == 9)
+            rc = pl.tile % 10 == 8 ? launch_conv_patch<T, 5>(p, pl, st) : launch_conv_patch<T, 4>(p, pl, st);
+        else if (pl.tile / 10 == 8)
             rc = pl.tile % 10 == 8 ? launch_tile_lw<T, 4, 5, 3, 4, 4>(p, pl, st) : launch_tile_lw<T, 4, 4, 3, 4, 4>(p, pl, st);
         else
             rc = pl.tile / 10 == 5 ? launch_lw_by_tile<T, 3, 4>(p, pl, st) : pl.tile / 10 == 6 ? launch_lw_by_tile<T, 3, 8>(p, pl, st)
@@ -1589,7 +1939,7 @@ static bool gemm_epilogue_emits_gn(const idb_gemm_desc* d, const Plan& pl, int g
     if ((pl.tile / 10 > 2 && pl.tile / 10 < 5) || d->geglu || !gemm_uses_lds_epilogue(d, pl)) return false;
     const TileCfg& t = kTiles[pl.tile % 10];
     const int epi_threads = d->gn_in_partials ? 256 : 128 * t.wm;      // the fused-GroupNorm kernel has 4 MFMA waves
-    return idb_epilogue_emits_gn(16 * t.mf * t.wm * (pl.tile / 10 == 8 ? 2 : 1), 32 * t.nf, epi_threads, pl.M, d->n, groups) && (long long)d->out_h * d->out_w % 64 == 0 &&
+    return idb_epilogue_emits_gn(16 * t.mf * t.wm * (pl.tile / 10 >= 8 ? 2 : 1), 32 * t.nf, epi_threads, pl.M, d->n, groups) && (long long)d->out_h * d->out_w % 64 == 0 &&
            d->out_ld == d->n;
 }
 
@@ -1761,7 +2111,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.w_group_rows = d->w_group_rows;
     p.w_group_stride = d->w_group_stride;
     if (p.w_groups > 1) {
-        const int bm_t = 16 * kTiles[pl.tile % 10].mf * kTiles[pl.tile % 10].wm * (pl.tile / 10 == 8 ? 2 : 1);
+        const int bm_t = 16 * kTiles[pl.tile % 10].mf * kTiles[pl.tile % 10].wm * (pl.tile / 10 >= 8 ? 2 : 1);
         IDB_REQUIRE(d->w_group_rows > 0 && d->w_group_stride >= (long long)p.w_bytes && d->w_group_stride % 16 == 0 &&
                         (long long)d->w_groups * d->w_group_stride < (1LL << 40), "idb_gemm: w_groups needs w_group_rows > 0 and a 16-byte-multiple w_group_stride >= one matrix");
         if (pl.tile / 10 == 4 || d->w_group_rows % bm_t != 0) {

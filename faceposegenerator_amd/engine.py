@@ -549,7 +549,7 @@ class HipEngine:
             d.w_groups, d.w_group_rows, d.w_group_stride = G, m // (rep * G), w.shape[1] * 2
             tile_id = C.c_int32()
             L.check(self.lib.idb_gemm_plan(C.byref(d), C.byref(tile_id), None, None), "idb_gemm_plan")
-            bm = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128, 6: 64, 7: 64, 8: 128, 9: 128}[tile_id.value % 10] * (2 if tile_id.value // 10 == 8 else 1)
+            bm = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128, 6: 64, 7: 64, 8: 128, 9: 128}[tile_id.value % 10] * (2 if tile_id.value // 10 >= 8 else 1)
             if tile_id.value // 10 == 4 or d.w_group_rows % bm:
                 # this launch will run group by group on row slices (_gemm_per_group): no row statistics out, no folded LayerNorm in
                 row_stats = False

@@ -673,6 +673,92 @@ def test_conv_256_row_loader_wave_tile_bit_identical_with_gn_partials(eng):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Patch-resident 3x3 conv (tile ids 98 / 99, idb_conv_patch_kernel): the halo patch of a 256-pixel tile loaded once per 64-channel
+# chunk, K walked chunk-major.  Different accumulation ORDER than the tap-major kernels, so: equal to the fp32 reference within the
+# operand tolerance, and within a few ulp of the tap-major 256-row tile (tile ids 88 / 89) — not bit-identical
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,h,w_,cin,cout,shape", [
+    (2, 64, 64, 64, 320, 8),      # 4 image rows per tile, 2 column tiles
+    (1, 64, 64, 320, 160, 8),     # 5 chunks x 9 taps: the double-buffered patch wraps
+    (4, 32, 32, 128, 256, 9),     # 8 image rows per tile, 256x128 tile
+    (3, 16, 16, 192, 320, 8),     # one whole image per tile
+    (8, 8, 8, 128, 160, 8),       # FOUR whole images per tile (halo rows between them)
+    (4, 8, 8, 64, 100, 9),        # ragged column tile (n = 100)
+    (2, 32, 16, 64, 128, 9)])     # non-square image: 16 rows of width 16 per tile, half an image
+def test_conv_patch_resident_tiles(eng, b, h, w_, cin, cout, shape):
+    x = _rand((b, h, w_, cin), 131).to(eng.tdt)
+    wc = _rand((cout, cin, 3, 3), 132, (9 * cin) ** -0.5)
+    w = eng.tile_weight(eng._pack_conv(wc))
+    bias = _rand((cout,), 133)
+    res = _rand((b * h * w_, cout), 134).to(eng.tdt) if cout % 8 == 0 else None
+    ref = eng.gemm([(x, cin, 9, h, w_, 0)], w, cout, b, h, w_, bias=bias, residual=res, tile=80 + shape)
+    out = eng.gemm([(x, cin, 9, h, w_, 0)], w, cout, b, h, w_, bias=bias, residual=res, tile=90 + shape)
+    torch.cuda.synchronize()
+    want = F.conv2d(x.float().permute(0, 3, 1, 2), wc.to(eng.tdt).float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    if res is not None:
+        want = want + res.float()
+    _check(out, want, _tol(eng), "patch conv")
+    ulp = 2.0 ** (-10 if eng.tdt == torch.float16 else -7)
+    assert (out.float() - ref.float()).abs().max().item() <= 2 * ulp * max(1.0, want.abs().max().item())
+    # the same through rows-layout weights
+    out_r = eng.gemm([(x, cin, 9, h, w_, 0)], eng._pack_conv(wc), cout, b, h, w_, bias=bias, residual=res, tile=90 + shape)
+    torch.cuda.synchronize()
+    assert torch.equal(out_r, out)
+
+
+def test_conv_patch_resident_with_shortcut_segments_and_gn_partials(eng):
+    """conv2 + 1x1 shortcut over a skip concatenation: a 9-tap segment followed by two halo-less 1-tap segments; GroupNorm-statistics
+    epilogue and a per-sample bias ride along."""
+    b, h, c1, c2, cout = 4, 32, 128, 64, 320
+    n2 = _rand((b, h, h, cout), 141).to(eng.tdt)
+    xa, xb = _rand((b, h, h, c1), 142).to(eng.tdt), _rand((b, h, h, c2), 143).to(eng.tdt)
+    wfull = _rand((cout, 9 * cout + c1 + c2), 144, (9 * cout) ** -0.5).to(eng.tdt)
+    w = eng.tile_weight(wfull)
+    bias = _rand((cout,), 145)
+    srcs = [(n2, cout, 9, h, h, 0), (xa, c1, 1, h, h, 0), (xb, c2, 1, h, h, 0)]
+    ref = eng.gemm(srcs, w, cout, b, h, h, bias=bias, tile=88, gn_stats=32)
+    out = eng.gemm(srcs, w, cout, b, h, h, bias=bias, tile=98, gn_stats=32)
+    torch.cuda.synchronize()
+    ulp = 2.0 ** (-10 if eng.tdt == torch.float16 else -7)
+    assert (out.float() - ref.float()).abs().max().item() <= 2 * ulp * max(1.0, ref.float().abs().max().item())
+    assert getattr(out, "_gn", None) is not None and getattr(ref, "_gn", None) is not None
+    assert torch.allclose(ref._gn[0], out._gn[0], rtol=2e-3, atol=0.5)
+    # against fp32: conv over the packed [cout][tap][cin] block + the two 1x1 blocks
+    wc = wfull[:, :9 * cout].float().reshape(cout, 3, 3, cout).permute(0, 3, 1, 2)
+    want = F.conv2d(n2.float().permute(0, 3, 1, 2), wc, bias, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    want = want + xa.float().reshape(-1, c1) @ wfull[:, 9 * cout:9 * cout + c1].float().t() + xb.float().reshape(-1, c2) @ wfull[:, 9 * cout + c1:].float().t()
+    _check(out, want, _tol(eng), "patch conv + shortcut segments")
+
+
+def test_conv_patch_planner_and_refusals(eng):
+    """auto plan: a large-grid 3x3 stride-1 conv takes the patch-resident tile (98); what it cannot run stays on the tap-major tile (auto)
+    or is refused (forced)."""
+    import ctypes as C
+    from faceposegenerator_amd import _lib as L
+
+    def plan(b, h, cin, cout, stride=1, up=0, taps=9, tile=0):
+        x = torch.empty((b, h >> up, h >> up, cin), dtype=eng.tdt, device="cuda")
+        w = torch.empty((cout, taps * cin), dtype=eng.tdt, device="cuda")
+        out = torch.empty((b * (h // stride) ** 2, cout), dtype=eng.tdt, device="cuda")
+        d = L.GemmDesc()
+        d.dtype, d.batch, d.out_h, d.out_w, d.stride, d.n, d.nsrc = eng.dt, b, h // stride, h // stride, stride, cout, 1
+        d.src[0].ptr, d.src[0].channels, d.src[0].taps, d.src[0].in_h, d.src[0].in_w, d.src[0].upsample = x.data_ptr(), cin, taps, h >> up, h >> up, up
+        d.w, d.out, d.out_dtype, d.out_ld, d.tile = w.data_ptr(), out.data_ptr(), eng.dt, cout, tile
+        t, sk, bl = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = eng.lib.idb_gemm_plan(C.byref(d), C.byref(t), C.byref(sk), C.byref(bl))
+        return rc, t.value, sk.value
+
+    assert plan(128, 64, 320, 320) == (0, 98, 1)                 # configs[2]'s conv 320->320 @64x64 (B_eff 128)
+    assert plan(128, 16, 1280, 1280) == (0, 98, 1)
+    assert plan(128, 64, 320, 320, stride=2)[1] == 88            # Downsample2D: tap-major
+    assert plan(128, 64, 640, 640, up=1)[1] == 88                # Upsample2D conv: tap-major
+    assert plan(128, 64, 1280, 320, taps=1)[1] == 88             # K = 1280 projection
+    assert plan(2, 64, 320, 320)[1] // 10 != 9                   # batch 1: one workgroup per CU plans
+    assert plan(128, 64, 320, 320, stride=2, tile=98)[0] == -2
+    assert plan(3, 8, 320, 320, tile=98)[0] == -2   # 192 pixels: not whole tiles
+
+
+# ---------------------------------------------------------------------------------------------------
 # GroupNorm(+SiLU) applied by normalizer waves inside the conv (idb_gemm_desc.gn_in_*): the transform is gn_apply_kernel's
 # arithmetic on the same partial sums, so the result must equal idb_groupnorm(partials_in) + idb_gemm BIT FOR BIT
 # ---------------------------------------------------------------------------------------------------

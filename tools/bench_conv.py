@@ -15,7 +15,7 @@ combos = [(0, 0), (16, 1), (18, 1), (18, 2), (18, 3), (18, 4), (18, 6), (18, 8),
 if os.environ.get("IDB_COMBOS"):        # e.g. IDB_COMBOS="0:0,6:2,6:4,8:4,8:8"  (tile:split_k)
     combos = [tuple(int(v) for v in c.split(":")) for c in os.environ["IDB_COMBOS"].split(",")]
 elif be >= 8:
-    combos = [(0, 0), (8, 1), (88, 1), (9, 1), (89, 1), (58, 1), (78, 1)]
+    combos = [(0, 0), (8, 1), (88, 1), (98, 1), (9, 1), (89, 1), (99, 1)]
 for (side, cin, cout) in shapes:
     m, k = be * side * side, 9 * cin
     per = 2 * (m * cin + cout * k + m * cout)
@@ -33,7 +33,10 @@ for (side, cin, cout) in shapes:
             continue
         def run(i):
             eng.gemm([(xs[i], cin, 9, side, side, 0)], ws[i], cout, be, side, side, out=outs[i], split_k=sk, tile=tile)
-        for i in range(nbuf): run(i)
+        try:
+            for i in range(nbuf): run(i)
+        except RuntimeError:                  # a forced tile the shape cannot run (IDB_EUNSUPPORTED)
+            continue
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
