@@ -501,37 +501,220 @@ __global__ __launch_bounds__(128 * WM + 64 * LW) void idb_gemm_kernel_lw(const G
 //   256 tile pixels and one tap per chunk.  Zero padding = out-of-range buffer offsets, as everywhere.
 // The accumulation order over K differs from the tap-major kernels, so results are equal to rounding, not bit-identical.
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int NF>
-__global__ __launch_bounds__(768) void idb_conv_patch_kernel(const GemmParams p) {
+// K-step g of the chunk-major K walk ([segment][chunk][tap]) -> segment s, chunk c, tap t, K-step base of that segment's weights
+__device__ __forceinline__ void idb_patch_seek(const GemmParams& p, int g, int& s, int& c, int& t, int& base) {
+    s = 0;
+    base = 0;
+    while (s < IDB_MAX_SRC - 1 && g >= p.src[s].taps * (p.src[s].C >> 6)) {
+        const int steps = p.src[s].taps * (p.src[s].C >> 6);
+        g -= steps;
+        base += steps;
+        ++s;
+    }
+    c = g / p.src[s].taps;
+    t = g - c * p.src[s].taps;
+}
+
+// MF = 4: 256-row tiles, 3-stage weight ring (large grids).  MF = 1 / 2: 64- / 128-row tiles, 4-stage ring, split-K by whole chunks
+// (the one-workgroup-per-CU plans of the batch-1 UNet): the patch is 3-4 image rows there, the saving is the 9x smaller activation
+// stream of a K-step whose weight stream is unchanged.
+// GN = true (north_star "conv3x3 + GroupNorm+SiLU fused"; ResnetBlock2D norm1+conv1 / norm2+conv2 via inference_ID-Booth.py:138): the
+// patch loaders become FOUR waves that fetch the raw patch into registers, apply y = silu(x * k[c] + h[c]) — gn_apply_kernel's arithmetic
+// on the same partial sums (k = rstd * gamma, h = beta - mean * k), so the MFMA waves read the operands idb_groupnorm would have written —
+// and store it to the patch buffer, one slice between each pair of the chunk's nine barriers.  The patch is normalised ONCE per chunk (the
+// tap-major idb_gemm_kernel_gn re-normalises every pixel for each of its nine taps and lost on every 3x3 conv); padding pixels stay zero.
+// Every K segment is a normalised 3x3 source and a tile lies inside one sample (host: gemm_fuses_gn).
+template <typename T, int MF, int NF, int NS, bool GN = false>
+__global__ __launch_bounds__(GN ? 896 : 768) void idb_conv_patch_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using V8 = typename Op<T>::v8;
-    constexpr int MF = 4, WM = 4, NS = 3;
-    constexpr int BM = 256, BN = 32 * NF;
-    constexpr int PATCH = 400 * 128;                           // bytes of one patch buffer (<= 400 pixels, host check)
-    constexpr int NPI = 25;                                    // 1 KB wave-instructions per patch-loader wave (400 px / 2 waves / 8)
+    constexpr int WM = 4;
+    constexpr int BM = 64 * MF, BN = 32 * NF;
+    constexpr int PL = GN ? 4 : 2;                             // patch-loader waves
+    constexpr int PP_PAD = MF == 1 ? (GN ? 224 : 208) : MF == 2 ? (GN ? 288 : 272) : 400;   // patch pixels, padded to the patch loaders' sweep of 8 * PL pixels (host: conv_patch_ok)
+    constexpr int PATCH = PP_PAD * 128;                        // bytes of one patch buffer
+    constexpr int NPI = PP_PAD / (8 * PL);                     // 16-byte-per-lane loads per patch-loader wave and chunk
     constexpr int NJ = BN / 16;                                // weight-row sweeps of the two weight loaders (8 rows per instruction)
     constexpr int BSTAGE = BN * 128;
-    static_assert(2 * PATCH + NS * BSTAGE <= 160 * 1024, "LDS");
+    static_assert(2 * PATCH + NS * BSTAGE + (GN ? 256 : 0) <= 160 * 1024 && (MF < 4 || !GN), "LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem + 2 * PATCH;
+    float2* gst = (float2*)(ring + NS * BSTAGE);               // GN: {mean, rstd} of the tile's sample, per group
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int wg;
-    {
+    int wg, kz;
+    if (p.xcd_mode == 0) {
         const int nwg = gridDim.x, orig = blockIdx.x;
         const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
         wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        kz = blockIdx.z;
+    } else {                                                   // one K-slice per XCD (group): see idb_gemm_kernel
+        const int X = gridDim.x;
+        const int lin = blockIdx.x + X * blockIdx.z;
+        const int xcd = lin & 7, j = lin >> 3;
+        if (p.xcd_mode == 1) {
+            kz = xcd + 8 * (j / X);
+            wg = j % X;
+        } else {
+            kz = xcd >> 1;
+            wg = (xcd & 1) * (X >> 1) + j;
+        }
     }
     const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = p.ktiles;
+    // this workgroup's K range in K-steps of the chunk-major walk (balanced; a split may start and end inside a chunk)
+    const int g0 = (int)(((long long)kz * p.ktiles) / p.splitk), g1 = (int)(((long long)(kz + 1) * p.ktiles) / p.splitk);
+    const int nk = g1 - g0;
+    int s0, c0, t0, base0;
+    idb_patch_seek(p, g0, s0, c0, t0, base0);
     // tile geometry: R image rows of width W; nimg whole images when the image is smaller than the tile
     const int W = p.OW, H = p.HW / W;
     const int nimg = p.HW >= BM ? 1 : BM / p.HW;
     const int RI = BM / W / nimg;                              // tile rows per image
 
-    if (wave >= 10) {
+    if constexpr (GN) {
+        if (wave >= 10) {
+            // ---------------- transforming patch loaders (registers -> normalise -> LDS) ----------------
+            const int pw = wave - 10;
+            const int q8 = lane >> 3;
+            const int b0 = m0 / p.HW, y0 = (m0 - b0 * p.HW) / W;
+            const int G = p.gn_in_groups, cpg = p.gn_in_c / G;
+            const int co = (lane & 7) ^ q8;                    // this lane's channel octet inside every chunk (pixel q has q & 7 == q8)
+            unsigned voff[NPI];
+            bool okp[NPI];
+            int seg = -1, cb = 0;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src[0].ptr, 0, p.src[0].bytes, IDB_RSRC_FLAGS);
+            auto setup = [&](int s) {
+                const GemmSrcK S = p.src[s];
+                rs = __builtin_amdgcn_make_buffer_rsrc((void*)S.ptr, 0, S.bytes, IDB_RSRC_FLAGS);
+                const int PW = W + 2, RIh = RI + 2;
+                const int PP = RIh * PW;
+#pragma unroll
+                for (int i = 0; i < NPI; ++i) {
+                    const int q = (i * PL + pw) * 8 + q8;
+                    const int pr = q / PW, px = q - pr * PW;
+                    const int y = y0 + pr - 1, x = px - 1;
+                    okp[i] = q < PP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                    const int pix = (b0 * H + y) * W + x;
+                    voff[i] = okp[i] ? (unsigned)pix * (unsigned)(S.C * 2) + (unsigned)(co * 16) : IDB_OOB;
+                }
+                cb = 0;
+                for (int q = 0; q < s; ++q) cb += p.src[q].C;   // first channel of source s inside the normalised concatenation
+                seg = s;
+            };
+            V8 raw[NPI];
+            f32x4 g0v, g1v, b0v, b1v;
+            float kk[8], hh[8];
+            int ch0 = 0;
+            auto fetch_gb = [&]() {                            // gamma / beta of this lane's 8 channels
+                g0v = *(const f32x4*)(p.gn_in_gamma + ch0), g1v = *(const f32x4*)(p.gn_in_gamma + ch0 + 4);
+                b0v = *(const f32x4*)(p.gn_in_beta + ch0), b1v = *(const f32x4*)(p.gn_in_beta + ch0 + 4);
+            };
+            auto fetch = [&](int s, int c) {                   // the raw patch: loads only
+                if (s != seg) setup(s);
+                ch0 = cb + c * 64 + co * 8;
+                const unsigned soff = (unsigned)c * 128u;
+#pragma unroll
+                for (int i = 0; i < NPI; ++i) raw[i] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], soff, 0));
+            };
+            auto coeffs = [&]() {                              // k = rstd * gamma, h = beta - mean * k (the first use of the loads above)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float2 st = gst[(ch0 + e) / cpg];
+                    kk[e] = st.y * (e < 4 ? g0v[e] : g1v[e - 4]);
+                    hh[e] = (e < 4 ? b0v[e] : b1v[e - 4]) - st.x * kk[e];
+                }
+            };
+            auto put = [&](int i, int buf) {
+                V8 o = raw[i];
+                if (okp[i]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float y = to_f32<T>(raw[i][e]) * kk[e] + hh[e];
+                        if (p.gn_in_silu) y = silu_f(y);
+                        o[e] = from_f32<T>(y);
+                    }
+                }
+                *(V8*)(smem + buf * PATCH + ((i * PL + pw) * 8 + q8) * 128 + (lane & 7) * 16) = o;
+            };
+            int s = s0, c = c0, t = t0, buf = 0, done = 0;
+            fetch(s, c);                                       // the first patch is in flight while the statistics are added up
+            {
+                // {mean, rstd} per group of this tile's sample: 8 lanes per group add the pixel-chunk partials in gn_apply_kernel's order
+                // (4 waves x 8 groups = one pass for GroupNorm(32))
+                for (int g0_ = pw * 8; g0_ < G; g0_ += 8 * PL) {
+                    const int g = min(g0_ + (lane >> 3), G - 1), sub = lane & 7;
+                    f32x2 pv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int ch = min(sub + 8 * u, p.gn_in_chunks - 1);
+                        pv[u] = *(const f32x2*)(p.gn_in_part + (((long long)b0 * p.gn_in_chunks + ch) * G + g) * 2);
+                    }
+                    float a = 0.f, q = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (sub + 8 * u < p.gn_in_chunks) {
+                            a += pv[u][0];
+                            q += pv[u][1];
+                        }
+                    }
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) {
+                        a += __shfl_xor(a, o, 64);
+                        q += __shfl_xor(q, o, 64);
+                    }
+                    if (g0_ + (lane >> 3) < G && sub == 0) {
+                        const double cnt = (double)p.HW * cpg;
+                        const double mean = (double)a / cnt;
+                        double var = (double)q / cnt - mean * mean;
+                        if (var < 0.0) var = 0.0;
+                        gst[g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gn_in_eps)));
+                    }
+                }
+            }
+            fetch_gb();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // barrier S: the statistics are in LDS
+            coeffs();
+#pragma unroll
+            for (int i = 0; i < NPI; ++i) put(i, 0);
+            while (done < nk) {
+                const int n = 9 - t < nk - done ? 9 - t : nk - done;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // first K-step of the chunk: its normalised patch is in LDS
+                done += n;
+                int s2 = s, c2 = c + 1;
+                if (c2 == (p.src[s].C >> 6)) { c2 = 0; if (s2 < IDB_MAX_SRC - 1) ++s2; }
+                if (done < nk) {
+                    fetch(s2, c2);
+                    fetch_gb();
+                    if (n == 9) {
+                        // a whole chunk ahead: the loads fly during the chunk's first three K-steps, then one slice of the next patch is
+                        // normalised and stored between each pair of the remaining barriers (the compiler's counted vmcnt: loads return in order)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            if (k == 3) coeffs();
+                            if (k >= 3) {
+#pragma unroll
+                                for (int i = (k - 3) * NPI / 5; i < (k - 2) * NPI / 5; ++i) put(i, buf ^ 1);
+                            }
+                            asm volatile("s_barrier" ::: "memory");
+                        }
+                    } else {                                   // a split boundary inside the chunk: everything at once
+                        coeffs();
+#pragma unroll
+                        for (int i = 0; i < NPI; ++i) put(i, buf ^ 1);
+                        for (int k = 1; k < n; ++k) asm volatile("s_barrier" ::: "memory");
+                    }
+                } else {
+                    for (int k = 1; k < n; ++k) asm volatile("s_barrier" ::: "memory");
+                }
+                s = s2; c = c2; t = 0; buf ^= 1;
+            }
+            return;
+        }
+        if (wave < 8) asm volatile("s_barrier" ::: "memory");  // barrier S (MFMA waves; the weight loaders pass it behind their first stages)
+    }
+    if (!GN && wave >= 10) {
         // ---------------- patch loaders ----------------
         const int pw = wave - 10;
         const int q8 = lane >> 3;
@@ -566,17 +749,18 @@ __global__ __launch_bounds__(768) void idb_conv_patch_kernel(const GemmParams p)
             for (int i = 0; i < NPI; ++i)
                 if (i < npi) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst + i * 2048), 16, voff[i], soff, 0, 0);
         };
-        int s = 0, c = 0, buf = 0, done = 0;
-        issue(0, 0, 0);
+        int s = s0, c = c0, t = t0, buf = 0, done = 0;
+        issue(s, c, 0);
         while (done < nk) {
             const int taps = p.src[s].taps, CS = p.src[s].C >> 6;
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // first tap of this chunk: its patch has landed
-            done += taps;
+            const int n = taps - t < nk - done ? taps - t : nk - done;          // this split's K-steps inside the chunk
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // first of them: the chunk's patch has landed
+            done += n;
             int s2 = s, c2 = c + 1;
-            if (c2 == CS) { c2 = 0; ++s2; }
+            if (c2 == CS) { c2 = 0; if (s2 < IDB_MAX_SRC - 1) ++s2; }
             if (done < nk) issue(s2, c2, buf ^ 1);             // into the buffer of the PREVIOUS chunk: every read of it is behind the barrier
-            for (int t = 1; t < taps; ++t) asm volatile("s_barrier" ::: "memory");
-            s = s2; c = c2; buf ^= 1;
+            for (int k = 1; k < n; ++k) asm volatile("s_barrier" ::: "memory");
+            s = s2; c = c2; t = 0; buf ^= 1;
         }
         return;
     }
@@ -592,8 +776,8 @@ __global__ __launch_bounds__(768) void idb_conv_patch_kernel(const GemmParams p)
             const int n = n0 + j * 16 + bw * 8 + lrow;
             w_voff[j] = n < p.N ? (unsigned)(n >> 4) * p.w_blk_bytes + (unsigned)(n & 15) * p.w_row_bytes + cg16 : IDB_OOB;
         }
-        int s = 0, c = 0, tap = 0, base = 0;
-        int taps = p.src[0].taps, CS = p.src[0].C >> 6;
+        int s = s0, c = c0, tap = t0, base = base0;
+        int taps = p.src[s].taps, CS = p.src[s].C >> 6;
         auto stage = [&](int buf) {
             char* sB = ring + buf * BSTAGE + bw * 1024;
             const unsigned soff = (unsigned)(base + tap * CS + c) * p.w_kstep;
@@ -613,6 +797,7 @@ __global__ __launch_bounds__(768) void idb_conv_patch_kernel(const GemmParams p)
 #pragma unroll
         for (int st = 0; st < NS - 1; ++st)
             if (st < nk) stage(st);
+        if constexpr (GN) asm volatile("s_barrier" ::: "memory");   // barrier S
         int cur = 0;
         for (int it = 0; it < nk; ++it) {
             if (it + NS - 2 < nk)
@@ -636,18 +821,18 @@ __global__ __launch_bounds__(768) void idb_conv_patch_kernel(const GemmParams p)
     int rr[MF], xx[MF];                                        // tile row -> (patch row without halo, x)
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-        const int ml = wm * 64 + i * 16 + fr;
+        const int ml = wm * 16 * MF + i * 16 + fr;
         const int r = ml / W;
         xx[i] = ml - r * W;
         rr[i] = r + 2 * (r / RI);                              // + 2 halo rows per image in front (9-tap segments only)
     }
     // K-step state (segment s, chunk c, tap t) and the half-step rotation around the barrier of idb_gemm_kernel_lw: the second 32-deep
     // half of a K-step is read before the barrier that publishes the next one and multiplied behind it
-    int cur = 0, pb = 0, s = 0, c = 0, t = 0, ky = 0, kx = 0;
-    int taps = p.src[0].taps, CS = p.src[0].C >> 6, h = taps == 9 ? 1 : 0, PW = W + 2 * h;
+    int cur = 0, pb = 0, s = s0, c = c0, t = t0, ky = t0 / 3, kx = t0 - 3 * (t0 / 3);
+    int taps = p.src[s].taps, CS = p.src[s].C >> 6, h = taps == 9 ? 1 : 0, PW = W + 2 * h;
     int pp0[MF];
 #pragma unroll
-    for (int i = 0; i < MF; ++i) pp0[i] = h ? rr[i] * PW + xx[i] : wm * 64 + i * 16 + fr;
+    for (int i = 0; i < MF; ++i) pp0[i] = h ? rr[i] * PW + xx[i] : wm * 16 * MF + i * 16 + fr;
     const int posw0 = (fg ^ (fr & 7)) * 16;
     const char* sBw = ring + (wn * 16 * NF + fr) * 128;
     unsigned a_addr[MF];
@@ -673,7 +858,7 @@ __global__ __launch_bounds__(768) void idb_conv_patch_kernel(const GemmParams p)
                 h = taps == 9 ? 1 : 0;
                 PW = W + 2 * h;
 #pragma unroll
-                for (int i = 0; i < MF; ++i) pp0[i] = h ? rr[i] * PW + xx[i] : wm * 64 + i * 16 + fr;
+                for (int i = 0; i < MF; ++i) pp0[i] = h ? rr[i] * PW + xx[i] : wm * 16 * MF + i * 16 + fr;
             }
         }
     };
@@ -723,7 +908,7 @@ __global__ __launch_bounds__(768) void idb_conv_patch_kernel(const GemmParams p)
 #pragma unroll
             for (int j = 0; j < NF; ++j) acc[i][j] = Op<T>::mfma16(wf1[j], af1[i], acc[i][j]);
     }
-    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, 0, false, make_float2(0.f, 0.f));
+    idb_gemm_epilogue<T, MF, NF, WM>(p, smem, acc, m0, n0, tid, wm, wn, fr, fg, kz, false, make_float2(0.f, 0.f));
 #endif
 }
 
@@ -1477,18 +1662,33 @@ struct Plan {
     long long K;
 };
 
-// idb_conv_patch_kernel's shapes: whole tiles of 256 output pixels that are whole image rows (or whole images), every K segment on the
-// output grid; the halo patch of one tile is at most 400 pixels
-static bool conv_patch_ok(const idb_gemm_desc* d, long long M) {
-    if (d->stride != 1 || d->pad_mode == 1 || d->geglu || d->ln_stats || d->gn_in_partials || d->split_k > 1 || d->nsrc < 1 || d->src[0].taps != 9) return false;
+// idb_conv_patch_kernel's shapes: whole tiles of bm (64 / 128 / 256) output pixels that are whole image rows (or whole images), every
+// K segment on the output grid; the halo patch of one tile fits the kernel's patch buffer (208 / 272 / 400 pixels)
+static bool conv_patch_ok(const idb_gemm_desc* d, long long M, int bm) {
+    if (d->stride != 1 || d->pad_mode == 1 || d->geglu || d->ln_stats || d->nsrc < 1 || d->src[0].taps != 9 || d->act) return false;
     const int W = d->out_w, H = d->out_h;
-    if (!(W == 8 || W == 16 || W == 32 || W == 64) || M % 256) return false;
+    if (!(W == 8 || W == 16 || W == 32 || W == 64) || W > bm || M % bm) return false;
     const long long HW = (long long)H * W;
-    if (!(HW % 256 == 0 || 256 % HW == 0)) return false;
-    const int nimg = HW >= 256 ? 1 : (int)(256 / HW);
-    if (nimg * (256 / W / nimg + 2) * (W + 2) > 400) return false;
-    for (int s = 0; s < d->nsrc; ++s)
+    if (!(HW % bm == 0 || bm % HW == 0)) return false;
+    const int nimg = HW >= bm ? 1 : (int)(bm / HW);
+    if (nimg * (bm / W / nimg + 2) * (W + 2) > (bm == 64 ? 208 : bm == 128 ? 272 : 400)) return false;
+    if (d->gn_in_partials) {
+        // fused GroupNorm (transforming patch loaders): small tiles inside ONE sample, every K segment a normalised 3x3 source
+        if (bm > 128 || HW < bm || d->gn_in_nsrc != d->nsrc || d->gn_in_groups <= 0 || d->gn_in_groups > 32 || d->gn_in_chunks < 1 || d->gn_in_chunks > 64) return false;
+        long long cn = 0;
+        for (int s = 0; s < d->nsrc; ++s) {
+            if (d->src[s].taps != 9) return false;
+            cn += d->src[s].channels;
+        }
+        if (cn % d->gn_in_groups) return false;
+    }
+    // 1x1 K segments (a fused conv_shortcut) run through the patch buffers with ONE K-step per chunk, i.e. on a two-deep pipeline:
+    // auto plans take the patch kernel for pure 3x3 convs only unless IDB_CONV_PATCH_SHORTCUT=1 (forced tile ids run every mix)
+    static const int env_sc = [] { const char* e = getenv("IDB_CONV_PATCH_SHORTCUT"); return e ? atoi(e) : 0; }();
+    for (int s = 0; s < d->nsrc; ++s) {
         if (d->src[s].upsample || d->src[s].in_h != H || d->src[s].in_w != W || d->src[s].channels % 64) return false;
+        if (d->src[s].taps != 9 && d->tile == 0 && !env_sc) return false;
+    }
     return true;
 }
 
@@ -1551,9 +1751,9 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     // 8 -> loader-wave variant with TWICE the rows (shapes 8 / 9 only: 256x160 / 256x128, 8 MFMA waves + 4 loader waves, 3-stage ring, one
     //      workgroup per CU with all 160 KB of LDS): 97 / 85 FLOP per byte moved L2 -> LDS instead of 73 for large grids
     const bool lw_tile = tile == 4 || (tile >= 6 && tile <= 9);
-    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 9 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
+    IDB_REQUIRE(d->tile >= 0 && tile <= kNumTiles && ring3 <= 10 && !(ring3 && tile == 0) && !((ring3 == 1 || ring3 == 2) && tile == 5) &&
                     !(ring3 == 4 && tile > 2) && !(ring3 > 1 && ring3 < 5 && (tile >= 6 || tile == 4)) && !(ring3 >= 5 && !lw_tile) &&
-                    !(ring3 >= 8 && tile < 8),
+                    !((ring3 == 8 || ring3 == 9) && tile < 8),
                 "idb_gemm: tile id out of range");
     const bool plain = d->nsrc == 1 && d->src[0].taps == 1 && d->src[0].in_h == 1 && d->src[0].in_w == 1;
     const bool pl_ok = plain && d->split_k <= 1 && d->out_dtype == d->dtype && (d->geglu ? d->n / 2 : d->n) % 4 == 0 &&
@@ -1646,15 +1846,20 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         if (env_big > 0 && blocks256 >= env_big) ring3 = 8;
         // 3x3 stride-1 convs on that plan: the patch-resident form (idb_conv_patch_kernel).  IDB_CONV_PATCH=0: tap-major 256-row tiles
         static const int env_patch = [] { const char* e = getenv("IDB_CONV_PATCH"); return e ? atoi(e) : 1; }();
-        if (ring3 == 8 && env_patch && conv_patch_ok(d, M)) ring3 = 9;
+        if (ring3 == 8 && env_patch && d->split_k <= 1 && conv_patch_ok(d, M, 256)) ring3 = 9;
     }
-    if (ring3 == 9 && !conv_patch_ok(d, M)) {
+    if (d->tile == 0 && ring3 >= 5 && ring3 <= 7 && !d->geglu) {
+        // the same for the one-workgroup-per-CU plans (64- / 128-row tiles, split-K by whole chunks): IDB_CONV_PATCH_SMALL=1
+        static const int env_ps = [] { const char* e = getenv("IDB_CONV_PATCH_SMALL"); return e ? atoi(e) : 0; }();
+        if ((env_ps || d->gn_in_partials) && conv_patch_ok(d, M, 16 * kTiles[tile].mf * kTiles[tile].wm)) ring3 = 10;
+    }
+    if ((ring3 == 9 && !(d->split_k <= 1 && conv_patch_ok(d, M, 256))) || (ring3 == 10 && !conv_patch_ok(d, M, 16 * kTiles[tile].mf * kTiles[tile].wm))) {
         idb_set_error("idb_gemm: tile %d (patch-resident conv) needs a 3x3 stride-1 pad-1 first source, 1x1 / 3x3 sources on the output grid without "
                       "upsampling, out_w in {8,16,32,64}, whole tiles of 256 pixels, no folded LayerNorm / fused GroupNorm / GEGLU / split-K", d->tile);
         return IDB_EUNSUPPORTED;
     }
     pl->tile = tile + 10 * ring3;
-    const int bm = 16 * kTiles[tile].mf * kTiles[tile].wm * (ring3 >= 8 ? 2 : 1), bn = 32 * kTiles[tile].nf;
+    const int bm = 16 * kTiles[tile].mf * kTiles[tile].wm * (ring3 == 8 || ring3 == 9 ? 2 : 1), bn = 32 * kTiles[tile].nf;
     pl->tiles_m = (int)((M + bm - 1) / bm);
     pl->tiles_n = (d->n + bn - 1) / bn;
     const long long blocks = (long long)pl->tiles_m * pl->tiles_n;
@@ -1662,7 +1867,7 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
     int sk = d->split_k;
     if (sk <= 0) {
         sk = 1;
-        const bool small_tile = kTiles[tile].mf * kTiles[tile].wm <= 4 && ring3 < 8;     // 64-row tiles
+        const bool small_tile = kTiles[tile].mf * kTiles[tile].wm <= 4 && ring3 != 8 && ring3 != 9;     // 64-row tiles
         if (auto_sk) {
             sk = auto_sk;
         } else if (!d->geglu && small_tile && blocks < 96 && pl->ktiles >= 10) {
@@ -1744,20 +1949,20 @@ int launch_tile_lw(const GemmParams& p, const Plan& pl, hipStream_t st) {
     return IDB_OK;
 }
 
-template <typename T, int NF>
+template <typename T, int MF, int NF, int NS, bool GN = false>
 int launch_conv_patch(const GemmParams& p, const Plan& pl, hipStream_t st) {
-    constexpr int LDS = 2 * 400 * 128 + 3 * 32 * NF * 128;
+    constexpr int LDS = 2 * (MF == 1 ? (GN ? 224 : 208) : MF == 2 ? (GN ? 288 : 272) : 400) * 128 + NS * 32 * NF * 128 + (GN ? 256 : 0);
     static_assert(LDS <= 160 * 1024, "patch buffers + weight ring do not fit");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_conv_patch_kernel<T, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&idb_conv_patch_kernel<T, MF, NF, NS, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             idb_set_error("idb_gemm: hipFuncSetAttribute(%d) failed: %s", LDS, hipGetErrorString(e));
             return IDB_EHIP;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((idb_conv_patch_kernel<T, NF>), dim3(pl.tiles_m * pl.tiles_n), dim3(768), LDS, st, p);
+    hipLaunchKernelGGL((idb_conv_patch_kernel<T, MF, NF, NS, GN>), dim3(pl.tiles_m * pl.tiles_n, 1, pl.splitk), dim3(GN ? 896 : 768), LDS, st, p);
     IDB_CHECK_LAUNCH("idb_gemm(patch)");
     return IDB_OK;
 }
@@ -1860,13 +2065,30 @@ template <typename T>
 int launch_all(const idb_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
     int rc;
     if (p.gn_in_part) {
-        rc = launch_gn_by_tile<T>(p, pl, st);
+        if (pl.tile / 10 == 10) {                              // the patch-resident conv with transforming patch loaders
+            switch (pl.tile % 10) {
+                case 4: rc = launch_conv_patch<T, 1, 2, 4, true>(p, pl, st); break;
+                case 6: rc = launch_conv_patch<T, 1, 5, 4, true>(p, pl, st); break;
+                case 7: rc = launch_conv_patch<T, 1, 4, 4, true>(p, pl, st); break;
+                case 8: rc = launch_conv_patch<T, 2, 5, 4, true>(p, pl, st); break;
+                default: rc = launch_conv_patch<T, 2, 4, 4, true>(p, pl, st); break;
+            }
+        } else
+            rc = launch_gn_by_tile<T>(p, pl, st);
         if (rc != IDB_OK || (d->flags & 1)) return rc;
         return idb_finish_splitk<T>(p, pl.M, d->n, d->batch, pl.splitk, d->gn_partials, d->gn_groups, d->dtype, st);
     }
     if (pl.tile / 10 >= 5) {
-        if (pl.tile / 10 == 9)
-            rc = pl.tile % 10 == 8 ? launch_conv_patch<T, 5>(p, pl, st) : launch_conv_patch<T, 4>(p, pl, st);
+        if (pl.tile / 10 == 10) {
+            switch (pl.tile % 10) {
+                case 4: rc = launch_conv_patch<T, 1, 2, 4>(p, pl, st); break;
+                case 6: rc = launch_conv_patch<T, 1, 5, 4>(p, pl, st); break;
+                case 7: rc = launch_conv_patch<T, 1, 4, 4>(p, pl, st); break;
+                case 8: rc = launch_conv_patch<T, 2, 5, 4>(p, pl, st); break;
+                default: rc = launch_conv_patch<T, 2, 4, 4>(p, pl, st); break;
+            }
+        } else if (pl.tile / 10 == 9)
+            rc = pl.tile % 10 == 8 ? launch_conv_patch<T, 4, 5, 3>(p, pl, st) : launch_conv_patch<T, 4, 4, 3>(p, pl, st);
         else if (pl.tile / 10 == 8)
             rc = pl.tile % 10 == 8 ? launch_tile_lw<T, 4, 5, 3, 4, 4>(p, pl, st) : launch_tile_lw<T, 4, 4, 3, 4, 4>(p, pl, st);
         else
@@ -1939,7 +2161,7 @@ static bool gemm_epilogue_emits_gn(const idb_gemm_desc* d, const Plan& pl, int g
     if ((pl.tile / 10 > 2 && pl.tile / 10 < 5) || d->geglu || !gemm_uses_lds_epilogue(d, pl)) return false;
     const TileCfg& t = kTiles[pl.tile % 10];
     const int epi_threads = d->gn_in_partials ? 256 : 128 * t.wm;      // the fused-GroupNorm kernel has 4 MFMA waves
-    return idb_epilogue_emits_gn(16 * t.mf * t.wm * (pl.tile / 10 >= 8 ? 2 : 1), 32 * t.nf, epi_threads, pl.M, d->n, groups) && (long long)d->out_h * d->out_w % 64 == 0 &&
+    return idb_epilogue_emits_gn(16 * t.mf * t.wm * (pl.tile / 10 == 8 || pl.tile / 10 == 9 ? 2 : 1), 32 * t.nf, epi_threads, pl.M, d->n, groups) && (long long)d->out_h * d->out_w % 64 == 0 &&
            d->out_ld == d->n;
 }
 
@@ -1954,6 +2176,11 @@ extern "C" int32_t idb_gemm_emits_gn_partials(const idb_gemm_desc* d, int32_t gr
 // the output grid, tiles inside one sample or covering whole samples, no folded LayerNorm on the same launch
 static bool gemm_fuses_gn(const idb_gemm_desc* d, const Plan& pl) {
     if (!d->gn_in_partials) return false;
+    if (pl.tile / 10 == 10) return conv_patch_ok(d, pl.M, 16 * kTiles[pl.tile % 10].mf * kTiles[pl.tile % 10].wm);
+    // the tap-major normalizer-wave kernel loses on every 3x3 conv (it re-normalises each pixel per tap): auto plans use it for 1x1 sources
+    // only (Transformer2DModel norm + proj_in); forced tile ids and IDB_GN_TAPMAJOR=1 still reach it for 3x3 sources
+    static const int env_tm = [] { const char* e = getenv("IDB_GN_TAPMAJOR"); return e ? atoi(e) : 0; }();
+    if (d->src[0].taps == 9 && d->tile == 0 && !env_tm) return false;
     if (pl.tile / 10 < 5 || pl.tile / 10 > 7 || d->stride != 1 || d->ln_stats || d->geglu || d->gn_in_nsrc < 1 || d->gn_in_nsrc > d->nsrc) return false;
     const int bm = 16 * kTiles[pl.tile % 10].mf * kTiles[pl.tile % 10].wm;
     if (bm != 64) return false;                        // 64x160 / 64x128 / 64x64 plans (launch_gn_by_tile)
@@ -2111,7 +2338,7 @@ extern "C" int idb_gemm(const idb_gemm_desc* d, void* workspace, size_t workspac
     p.w_group_rows = d->w_group_rows;
     p.w_group_stride = d->w_group_stride;
     if (p.w_groups > 1) {
-        const int bm_t = 16 * kTiles[pl.tile % 10].mf * kTiles[pl.tile % 10].wm * (pl.tile / 10 >= 8 ? 2 : 1);
+        const int bm_t = 16 * kTiles[pl.tile % 10].mf * kTiles[pl.tile % 10].wm * (pl.tile / 10 == 8 || pl.tile / 10 == 9 ? 2 : 1);
         IDB_REQUIRE(d->w_group_rows > 0 && d->w_group_stride >= (long long)p.w_bytes && d->w_group_stride % 16 == 0 &&
                         (long long)d->w_groups * d->w_group_stride < (1LL << 40), "idb_gemm: w_groups needs w_group_rows > 0 and a 16-byte-multiple w_group_stride >= one matrix");
         if (pl.tile / 10 == 4 || d->w_group_rows % bm_t != 0) {

@@ -130,10 +130,12 @@ class HipEngine:
         # one-workgroup-per-CU loader-wave plan (the batch-1 UNet); IDB_GN_CONV=0: idb_groupnorm + idb_gemm everywhere
         self._gn_conv = os.environ.get("IDB_GN_CONV", "1") != "0" and dtype != "fp8"
         # measured per shape at B_eff 2 (tools/bench_gnfuse.py, profiles/r03): Transformer2DModel.norm + proj_in at the 64x64 level 17.9 ->
-        # 13.3 us (no SiLU, 5 K-steps, 320-channel table); every 3x3 conv LOSES (34 -> 44 us on conv 320->320: with 4 MFMA waves per
-        # workgroup the fragment reads are no longer hidden, and every tap re-normalises its pixels), deeper proj_in lose to the table
-        # prologue.  So the resnet convs keep idb_groupnorm + idb_gemm unless IDB_GN_CONV_RESNET=1, proj_in fuses up to 320 channels
-        self._gn_conv_resnet = os.environ.get("IDB_GN_CONV_RESNET", "0") == "1"
+        # 13.3 us (no SiLU, 5 K-steps, 320-channel table); every 3x3 conv LOSES in that tap-major form (34 -> 44 us on conv 320->320: every
+        # tap re-normalises its pixels), deeper proj_in lose to the table prologue: proj_in fuses up to 320 channels.  The resnet convs
+        # fuse through the PATCH-resident conv instead (idb_conv_patch_kernel<GN>: the patch loaders normalise each halo patch once per
+        # chunk): 38 of the 44 gn_apply launches per CFG forward disappear, the fused convs cost 3-4 us more each; batch 1 +0.5 %
+        # (6.592 -> 6.622 / 6.632 images/s, one box).  IDB_GN_CONV_RESNET=0: idb_groupnorm + idb_gemm for every resnet conv
+        self._gn_conv_resnet = os.environ.get("IDB_GN_CONV_RESNET", "1") == "1"
         self._gn_conv_max_c = int(os.environ.get("IDB_GN_CONV_MAX_C", "320"))
         self._gn_conv_cache: Dict[tuple, bool] = {}
         # weights in the K-tiled 16-row-block layout (idb_tile_weight): a workgroup's K loop reads each of its row blocks as one

@@ -132,10 +132,12 @@ typedef struct {
      * norm2+conv2(+conv_shortcut), Transformer2DModel norm+proj_in): the first gn_in_nsrc sources hold the RAW tensors; their channel
      * concatenation is normalised with nn.GroupNorm(gn_in_groups, eps) from gn_in_partials (the statistics idb_groupnorm takes as
      * partials_in: [batch][gn_in_chunks][gn_in_groups][2], gn_in_chunks <= 64), gamma / beta over those channels, then SiLU if
-     * gn_in_silu — by dedicated normalizer waves inside the kernel, bit-identical to idb_groupnorm followed by idb_gemm; zero padding
-     * stays zero.  Only plans that run one workgroup per CU take it (small grids: the batch-1 UNet): idb_gemm_fuses_groupnorm tells
-     * beforehand, idb_gemm returns IDB_EUNSUPPORTED otherwise and the caller runs idb_groupnorm + idb_gemm.  Needs stride 1, sources
-     * with the output's spatial grid, out_h*out_w a multiple or a divisor of the tile height.  NULL: off. */
+     * gn_in_silu — inside the kernel, with idb_groupnorm's arithmetic (the MFMA waves read the operand bits idb_groupnorm would have
+     * written); zero padding stays zero.  Two forms, both for plans that run one workgroup per CU (small grids: the batch-1 UNet):
+     * 3x3 sources (every source normalised, 64- / 128-row tiles inside one sample) go through the patch-resident conv, whose patch
+     * loaders normalise each halo patch once per 64-channel chunk (tile ids 10x); 1x1 sources (proj_in) through dedicated normalizer
+     * waves on the landed LDS stage (tile ids 5x-7x).  idb_gemm_fuses_groupnorm tells beforehand, idb_gemm returns IDB_EUNSUPPORTED
+     * otherwise and the caller runs idb_groupnorm + idb_gemm.  Needs stride 1 and sources on the output's spatial grid.  NULL: off. */
     const float* gn_in_partials;
     int32_t gn_in_chunks, gn_in_groups, gn_in_nsrc, gn_in_silu;
     float gn_in_eps;
@@ -145,8 +147,10 @@ typedef struct {
 
 size_t idb_gemm_workspace_bytes(const idb_gemm_desc* d);
 /* What idb_gemm would launch for `d`: tile config id (shape + 10 * variant; shapes 1: 128x160, 2: 128x128, 3: 64x160,
- * 4: 64x64 (8 waves), 5: 128x32, 6-9: 64x160 / 64x128 / 128x160 / 128x128 with 8 waves; variant 0/1: 2-/3-stage LDS ring,
- * 4: persistent), split-K factor and workgroup count.  Host-only, no GPU call. */
+ * 4: 64x64 (8 waves), 5: 128x32, 6-9: 64x160 / 64x128 / 128x160 / 128x128 with 8 waves; variant 0/1/2: 2-/3-/4-stage LDS ring,
+ * 3: register-staged, 4: persistent, 5-7: loader waves, 8: loader waves with 256-row tiles (shapes 8/9), 9: patch-resident 3x3 conv
+ * on 256-row tiles, 10: patch-resident 3x3 conv on the shape's own 64-/128-row tile), split-K factor and workgroup count.
+ * Host-only, no GPU call. */
 int idb_gemm_plan(const idb_gemm_desc* d, int32_t* tile, int32_t* split_k, int32_t* blocks);
 /* Column tiles of the plan idb_gemm would run for `d` if that plan can emit row statistics (LDS-staged epilogue), else 0. */
 int32_t idb_gemm_row_stats_tiles(const idb_gemm_desc* d);

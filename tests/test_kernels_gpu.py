@@ -706,6 +706,34 @@ def test_conv_patch_resident_tiles(eng, b, h, w_, cin, cout, shape):
     assert torch.equal(out_r, out)
 
 
+@pytest.mark.parametrize("b,h,w_,cin,cout,shape,split_k", [
+    (2, 64, 64, 64, 320, 6, 1),      # 64x160 tile = ONE image row, 3-row patch
+    (2, 64, 64, 192, 160, 8, 1),     # 128x160 tile = two image rows
+    (2, 32, 32, 128, 256, 7, 2),     # split-K: a split may start inside a chunk
+    (2, 16, 16, 320, 320, 8, 4),     # 45 K-steps over 4 splits: splits start mid-chunk
+    (2, 8, 8, 128, 160, 6, 2),       # 64 rows = one whole 8x8 image
+    (4, 8, 8, 192, 320, 8, 3),       # 128 rows = two whole images
+    (1, 16, 16, 192, 64, 4, 3),      # 64x64 tile
+    (2, 32, 32, 192, 256, 9, 1)])    # 128x128 tile
+def test_conv_patch_resident_small_tiles_and_split_k(eng, b, h, w_, cin, cout, shape, split_k):
+    """tile ids 10x: the patch-resident conv on the 64- / 128-row tiles of the one-workgroup-per-CU plans, split-K over K-steps of the chunk-major walk."""
+    x = _rand((b, h, w_, cin), 151).to(eng.tdt)
+    wc = _rand((cout, cin, 3, 3), 152, (9 * cin) ** -0.5)
+    w = eng.tile_weight(eng._pack_conv(wc))
+    bias = _rand((cout,), 153)
+    res = _rand((b * h * w_, cout), 154).to(eng.tdt)
+    ref = eng.gemm([(x, cin, 9, h, w_, 0)], w, cout, b, h, w_, bias=bias, residual=res, tile=70 + shape, split_k=split_k, gn_stats=32 if cout % 32 == 0 else 0)
+    out = eng.gemm([(x, cin, 9, h, w_, 0)], w, cout, b, h, w_, bias=bias, residual=res, tile=100 + shape, split_k=split_k, gn_stats=32 if cout % 32 == 0 else 0)
+    torch.cuda.synchronize()
+    want = F.conv2d(x.float().permute(0, 3, 1, 2), wc.to(eng.tdt).float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + res.float()
+    _check(out, want, _tol(eng), "patch conv, small tile")
+    ulp = 2.0 ** (-10 if eng.tdt == torch.float16 else -7)
+    assert (out.float() - ref.float()).abs().max().item() <= 2 * ulp * max(1.0, want.abs().max().item())
+    assert (getattr(ref, "_gn", None) is None) == (getattr(out, "_gn", None) is None)
+    if getattr(ref, "_gn", None) is not None:
+        assert torch.allclose(ref._gn[0], out._gn[0], rtol=2e-3, atol=0.5)
+
+
 def test_conv_patch_resident_with_shortcut_segments_and_gn_partials(eng):
     """conv2 + 1x1 shortcut over a skip concatenation: a 9-tap segment followed by two halo-less 1-tap segments; GroupNorm-statistics
     epilogue and a per-sample bias ride along."""
@@ -762,7 +790,7 @@ def test_conv_patch_planner_and_refusals(eng):
 # GroupNorm(+SiLU) applied by normalizer waves inside the conv (idb_gemm_desc.gn_in_*): the transform is gn_apply_kernel's
 # arithmetic on the same partial sums, so the result must equal idb_groupnorm(partials_in) + idb_gemm BIT FOR BIT
 # ---------------------------------------------------------------------------------------------------
-def _gn_ref_and_fused(eng, srcs_raw, c_norm, nsrc_norm, w, cout, b, h, w_, tile, silu, eps, seed, extra=None, split_k=0, **kw):
+def _gn_ref_and_fused(eng, srcs_raw, c_norm, nsrc_norm, w, cout, b, h, w_, tile, silu, eps, seed, extra=None, split_k=0, ref_tile=None, **kw):
     """srcs_raw: [(tensor [b,h,w,c], c, taps)]; the first nsrc_norm are normalised as one GroupNorm(32) over their concatenation."""
     G = 32
     gamma, beta = 1.0 + 0.3 * _rand((c_norm,), seed), 0.2 * _rand((c_norm,), seed + 1)
@@ -791,7 +819,7 @@ def _gn_ref_and_fused(eng, srcs_raw, c_norm, nsrc_norm, w, cout, b, h, w_, tile,
         wref = kw.pop("w_ref")
     else:
         wref = w
-    ref = eng.gemm(ref_srcs, wref, cout, b, h, w_, tile=tile - (tile // 10) * 10 + 10, split_k=split_k, **(extra or {}))
+    ref = eng.gemm(ref_srcs, wref, cout, b, h, w_, tile=ref_tile or (tile - (tile // 10) * 10 + 10), split_k=split_k, **(extra or {}))
     fused = eng.gemm([(t, c, tp, h, w_, 0) for (t, c, tp) in srcs_raw], w, cout, b, h, w_, tile=tile, split_k=split_k,
                      gn_in=(part, chunks, G, eps, gamma, beta, silu, nsrc_norm), **(extra or {}))
     torch.cuda.synchronize()
@@ -835,6 +863,51 @@ def test_fused_groupnorm_over_skip_concat_and_shortcut(eng):
     assert (getattr(fused, "_gn", None) is None) == (getattr(ref, "_gn", None) is None)
     if getattr(fused, "_gn", None) is not None:
         assert torch.allclose(fused._gn[0], ref._gn[0], rtol=1e-5, atol=1e-2)
+
+
+@pytest.mark.parametrize("b,h,cin,cout,shape,split_k", [(2, 64, 128, 320, 6, 1), (2, 64, 64, 160, 8, 1), (2, 32, 256, 256, 9, 2), (1, 16, 320, 320, 8, 4),
+                                                         (2, 8, 256, 160, 6, 2), (2, 16, 192, 64, 4, 3), (3, 32, 192, 128, 7, 1)])
+def test_fused_groupnorm_silu_in_patch_resident_conv_bit_identical(eng, b, h, cin, cout, shape, split_k):
+    """tile ids 10x with gn_in: the transforming patch loaders normalise each halo patch once per chunk; operands and accumulation order are
+    those of idb_groupnorm + the unfused patch-resident conv, so the result is bit-identical (padding pixels stay zero)."""
+    x = _rand((b, h, h, cin), 161, 1.5).to(eng.tdt)
+    w = eng.tile_weight(eng._pack_conv(_rand((cout, cin, 3, 3), 162, (9 * cin) ** -0.5)))
+    bias, sb = _rand((cout,), 163), _rand((b, cout), 164)
+    res = _rand((b * h * h, cout), 165).to(eng.tdt)
+    for silu in (True, False):
+        ref, fused = _gn_ref_and_fused(eng, [(x, cin, 9)], cin, 1, w, cout, b, h, h, 100 + shape, silu, 1e-5, 166,
+                                       extra=dict(bias=bias, sbias=(sb, 0, cout), residual=res, gn_stats=32 if cout % 32 == 0 else 0),
+                                       split_k=split_k, ref_tile=100 + shape)
+        assert torch.equal(fused, ref)
+    # the auto plan takes the same kernel when a GroupNorm is handed in
+    if eng.fuses_groupnorm([(cin, 9)], w, cout, b, h, h, 32, 1):
+        auto = eng.gemm([(x, cin, 9, h, h, 0)], w, cout, b, h, h, bias=bias, sbias=(sb, 0, cout), residual=res,
+                        gn_in=_last_gn_in(eng, x, cin, b, h, False, 166))
+        torch.cuda.synchronize()
+        assert (auto.float() - ref.float()).abs().max().item() <= 4 * _tol(eng) * max(1.0, ref.float().abs().max().item())
+
+
+def _last_gn_in(eng, x, cin, b, h, silu, seed):
+    G = 32
+    gamma, beta = 1.0 + 0.3 * _rand((cin,), seed), 0.2 * _rand((cin,), seed + 1)
+    xf = x.float().reshape(b, h * h // 64, 64, G, cin // G)
+    part = torch.stack([xf.sum(dim=(2, 4)), (xf * xf).sum(dim=(2, 4))], dim=-1).contiguous()
+    return (part, h * h // 64, G, 1e-5, gamma, beta, silu, 1)
+
+
+def test_fused_groupnorm_over_skip_concat_in_patch_resident_conv(eng):
+    """norm1 + conv1 over cat[x, skip] as two normalised 3x3 K segments of the patch-resident conv."""
+    b, h, ca, cb, cout = 2, 16, 128, 64, 192
+    xa, xb = _rand((b, h, h, ca), 171).to(eng.tdt), _rand((b, h, h, cb), 172, 2.0).to(eng.tdt)
+    wc = _rand((cout, ca + cb, 3, 3), 173, (9 * (ca + cb)) ** -0.5)
+    w_ref = eng.tile_weight(eng._pack_conv(wc))
+    w_split = eng.tile_weight(torch.cat([eng._pack_conv(wc[:, :ca].contiguous()), eng._pack_conv(wc[:, ca:].contiguous())], dim=1).contiguous())
+    bias = _rand((cout,), 174)
+    ref, fused = _gn_ref_and_fused(eng, [(xa, ca, 9), (xb, cb, 9)], ca + cb, 2, w_split, cout, b, h, h, 106, True, 1e-5, 175, extra=dict(bias=bias),
+                                   w_ref=w_ref, ref_tile=106)
+    # statistics from two different first passes: equal up to an output ulp here and there
+    assert (fused.float() - ref.float()).abs().max().item() <= _tol(eng) * max(1.0, ref.float().abs().max().item())
+    assert (fused != ref).float().mean().item() < 0.02
 
 
 def test_fused_groupnorm_proj_in_no_silu_with_row_stats(eng):

@@ -8,7 +8,7 @@ BENCH1="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-ro
 step b1_fetch.log timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE -M --output-format csv -d $O/b1_fetch -- $BENCH1
 step b1_write.log timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE -M --output-format csv -d $O/b1_write -- $BENCH1
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"
-for t in 8 88; do
+for t in 88 98; do
 step conv_t${t}_sq.log timeout -k 10 300 rocprofv3 --pmc $SQ -M --output-format csv -d $O/conv_t${t}_sq -- python $R/tools/profile_gemm.py 128 10 $t
 step conv_t${t}_fetch.log timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -M --output-format csv -d $O/conv_t${t}_fetch -- python $R/tools/profile_gemm.py 128 10 $t
 step conv_t${t}_write.log timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -M --output-format csv -d $O/conv_t${t}_write -- python $R/tools/profile_gemm.py 128 10 $t
@@ -18,7 +18,7 @@ SQA="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_W
 step attn_sq.log timeout -k 10 300 rocprofv3 --pmc $SQA -M --output-format csv -d $O/attn_sq -- python $R/tools/profile_attn.py 128
 step attn_trace.log timeout -k 10 300 rocprofv3 --kernel-trace --stats -M --output-format csv -d $O/attn_trace -- python $R/tools/profile_attn.py 128
 cd $R
-for d in b1_fetch b1_write conv_t8_sq conv_t8_fetch conv_t8_write conv_t88_sq conv_t88_fetch conv_t88_write attn_sq; do
+for d in b1_fetch b1_write conv_t88_sq conv_t88_fetch conv_t88_write conv_t98_sq conv_t98_fetch conv_t98_write attn_sq; do
   f=$(find $O/$d -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f --json $O/$d.json > $O/$d.txt 2>&1
 done
