@@ -39,16 +39,22 @@ _TILE_SHAPES = {1: "128x160", 2: "128x128", 3: "64x160", 4: "64x64,8w", 5: "128x
 _TILE_VARIANTS = {0: "idb_gemm_kernel<{},ring2>", 1: "idb_gemm_kernel<{},ring3>", 2: "idb_gemm_kernel<{},ring4>",
                   3: "idb_gemm_kernel_rs<{}>", 4: "idb_gemm_kernel_pl<{}>", 5: "idb_gemm_kernel_lw<{},4 loader waves,ring3>",
                   6: "idb_gemm_kernel_lw<{},8 loader waves,ring3>", 7: "idb_gemm_kernel_lw<{},4 loader waves,ring4>",
-                  8: "idb_gemm_kernel_lw<{},4 loader waves,ring3>", 9: "idb_conv_patch_kernel<{},halo patch resident,2+2 loader waves>"}
+                  8: "idb_gemm_kernel_lw<{},4 loader waves,ring3>", 9: "idb_conv_patch_kernel<{},halo patch resident,2+2 loader waves>",
+                  10: "idb_conv_patch_kernel<{},halo patch resident,2+2 loader waves,ring4>"}
 
 
 class _TileNames(dict):
     """idb_gemm_plan tile id -> kernel instance name (id = shape + 10 * variant, see idb_gemm.hip)."""
     def __missing__(self, t):
+        gn, t = t >= 1000, t % 1000                        # + 1000: the launch carried a fused GroupNorm (engine launch log)
         shape = _TILE_SHAPES[t % 10]
-        if t // 10 >= 8:                                   # the 256-row loader-wave tiles
+        if t // 10 in (8, 9):                              # the 256-row loader-wave tiles
             shape = shape.replace("128x", "256x", 1)
-        return _TILE_VARIANTS[t // 10].format(shape)
+        name = _TILE_VARIANTS[t // 10].format(shape)
+        if gn:
+            name = (name.replace("2+2 loader waves", "2 weight-loader + 4 transforming patch-loader waves: GroupNorm+SiLU fused") if t // 10 == 10
+                    else name.replace("idb_gemm_kernel_lw<", "idb_gemm_kernel_gn<").replace("4 loader waves", "4 loader + 8 normalizer waves: GroupNorm fused"))
+        return name
 
 
 TILE_NAMES = _TileNames()
@@ -228,14 +234,19 @@ _KTILES = {1: (4, 5, 2), 2: (4, 4, 2), 3: (2, 5, 2), 4: (1, 2, 4), 5: (4, 1, 2),
 def mangled_gemm_name(tile: int, dtype: str) -> str:
     """Kernel symbol of an idb_gemm_plan tile id as rocprofv3 -M lists it (idb_gemm.hip: kTiles, launch_all)."""
     t = "DF16b" if dtype == "bf16" else "DF16_"
+    gn, tile = tile >= 1000, tile % 1000
     mf, nf, wm = _KTILES[tile % 10]
     v = tile // 10
+    if v == 10:                                            # idb_conv_patch_kernel<T, MF, NF, NS, GN> on the shape's own tile (MF = rows / 64)
+        return f"idb_conv_patch_kernelI{t}Li{mf * wm // 4}ELi{nf}ELi4ELb{int(gn)}EE"
+    if gn:                                                 # idb_gemm_kernel_gn<T, MF, NF, NS, WM, NV>: 4 MFMA waves (2 x 2)
+        return f"idb_gemm_kernel_gnI{t}Li2ELi{nf}ELi4ELi2ELi8EE"
     if v == 3:
         return f"idb_gemm_kernel_rsI{t}Li{mf}ELi{nf}EE"
     if v == 4:
         return f"idb_gemm_kernel_plI{t}Li{mf}ELi{nf}EE"
-    if v == 9:                                             # idb_conv_patch_kernel<T, NF>
-        return f"idb_conv_patch_kernelI{t}Li{nf}EE"
+    if v == 9:                                             # idb_conv_patch_kernel<T, 4, NF, 3, false>
+        return f"idb_conv_patch_kernelI{t}Li4ELi{nf}ELi3ELb0EE"
     if v >= 5:                                             # idb_gemm_kernel_lw<T, MF, NF, NS, WM, LW>
         ns, lw = {5: (3, 4), 6: (3, 8), 7: (4, 4), 8: (3, 4)}[v]
         return f"idb_gemm_kernel_lwI{t}Li{mf * (2 if v == 8 else 1)}ELi{nf}ELi{ns}ELi{wm}ELi{lw}EE"

@@ -23,9 +23,9 @@ def short(n):
                 if cfg == (mf // 2 if big else mf, nf, wm) and (not big or mf % 2 == 0) and shape in ((8, 9) if big else (4, 6, 7, 8, 9)):
                     v = 8 if big else {(3, 4): 5, (3, 8): 6, (4, 4): 7}[(ns, lw)]
                     return bench.TILE_NAMES[10 * v + shape]
-    m = re.search(r"idb_conv_patch_kernelI(DF16b|DF16_)Li(\d)E", n)
+    m = re.search(r"idb_conv_patch_kernelI(DF16b|DF16_)Li(\d)ELi(\d)ELi(\d)ELb(\d)E", n)
     if m:
-        return f"idb_conv_patch_kernel<256x{32 * int(m.group(2))}>"
+        return f"idb_conv_patch_kernel<{64 * int(m.group(2))}x{32 * int(m.group(3))}" + (",GroupNorm fused>" if m.group(5) == "1" else ">")
     m = re.search(r"idb_gemm_kernel(_rs|_pl)?I(DF16b|DF16_)Li(\d)ELi(\d)E(?:Li(\d)E)?(?:Li(\d)E)?", n)
     if m:
         wm = int(m.group(6) or 2)
