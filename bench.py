@@ -225,6 +225,13 @@ def kernel_roofline(eng, batch, lat_side, n_ctx):
             "launches_per_forward": a["n"], "avg_launch_us": round(a["ms"] * 1e3 / a["n"], 2),
             "flops_per_launch_avg": round(a["flops"] / a["n"], 1), "event_pair_overhead_us": round(overhead_ms * 1e3, 2),
             "all_gemm_tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 1), "launches_per_cfg_forward_all_kernels": eng.last_forward_launches,
+            # the next two kernels by total time, in the same units (the dominant one is a kernel INSTANCE: when launches move to another
+            # instance — e.g. the resnet convs that now run as the fused-GroupNorm patch conv — the mix behind `achieved` changes with them)
+            "next_by_time": [{"kernel": TILE_NAMES[t], "launches": agg[t]["n"], "share_of_gemm_time": round(agg[t]["ms"] / total_ms, 3),
+                              "achieved": round(agg[t]["flops"] / (agg[t]["ms"] * 1e-3) / 1e12, 1),
+                              "frac": round(agg[t]["flops"] / (agg[t]["ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4)}
+                             for t in sorted(agg, key=lambda t: -agg[t]["ms"])[1:3]],
+            "share_of_gemm_time": round(a["ms"] / total_ms, 3),
             "per_tile": detail}, dom
 
 
