@@ -1789,7 +1789,17 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
             if (sk > cap) sk = cap;
             if (sk > 32) sk = 32;
             if (sk < 1) sk = 1;
-            if (blocks_big * sk >= 128) {
+            if (M <= 128 && M > 64) {
+                // ONE 128-row tile of rows (the 8x8 level at batch 1): two 64-row tiles with half the split reach 256 workgroups where the
+                // 128-row plan stops at 192, and their slabs are half as many — conv 1280->1280 @8x8 21.7 -> 19.0 us, 2560->1280 26.2 -> 26.0
+                // (tools/bench_conv.py 2); a 64-row tile also lies inside one 8x8 sample, so the GroupNorm in front of it can fuse
+                tile = n160 ? 6 : 7;
+                const long long b64 = 2 * ((d->n + 32 * kTiles[tile].nf - 1) / (32 * kTiles[tile].nf));
+                sk = (int)(256 / b64);
+                if (sk > cap) sk = cap;
+                if (sk > 32) sk = 32;
+                auto_sk = sk < 1 ? 1 : sk;
+            } else if (blocks_big * sk >= 128) {
                 tile = n160 ? 8 : 9;
                 auto_sk = sk;
                 if (n160 && sk == 2 && pl->ktiles < 64) { tile = 6; auto_sk = 1; }   // 64x160: the same 256 workgroups without a reduce launch
