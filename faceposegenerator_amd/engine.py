@@ -133,7 +133,7 @@ class HipEngine:
         # 13.3 us (no SiLU, 5 K-steps, 320-channel table); every 3x3 conv LOSES in that tap-major form (34 -> 44 us on conv 320->320: every
         # tap re-normalises its pixels), deeper proj_in lose to the table prologue: proj_in fuses up to 320 channels.  The resnet convs
         # fuse through the PATCH-resident conv instead (idb_conv_patch_kernel<GN>: the patch loaders normalise each halo patch once per
-        # chunk): 19 of the 44 resnet convs per CFG forward fuse and lose their gn_apply launch, the fused convs cost 3-7 us more each; batch 1 +0.5 %
+        # chunk): 30 of the 44 resnet convs per CFG forward fuse and lose their gn_apply launch, the fused convs cost 3-7 us more each; batch 1 +0.5 %
         # (6.592 -> 6.622 / 6.632 images/s, one box).  IDB_GN_CONV_RESNET=0: idb_groupnorm + idb_gemm for every resnet conv
         self._gn_conv_resnet = os.environ.get("IDB_GN_CONV_RESNET", "1") == "1"
         self._gn_conv_max_c = int(os.environ.get("IDB_GN_CONV_MAX_C", "320"))

@@ -24,8 +24,13 @@ def short(n):
                     v = 8 if big else {(3, 4): 5, (3, 8): 6, (4, 4): 7}[(ns, lw)]
                     return bench.TILE_NAMES[10 * v + shape]
     m = re.search(r"idb_conv_patch_kernelI(DF16b|DF16_)Li(\d)ELi(\d)ELi(\d)ELb(\d)E", n)
-    if m:
-        return f"idb_conv_patch_kernel<{64 * int(m.group(2))}x{32 * int(m.group(3))}" + (",GroupNorm fused>" if m.group(5) == "1" else ">")
+    if m:                                       # patch-resident conv: the display names of bench.TILE_NAMES (tile ids 9x / 10x, + 1000 with a fused GroupNorm)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        mf, nf, gn = int(m.group(2)), int(m.group(3)), m.group(5) == "1"
+        shape = {(1, 2): 4, (1, 5): 6, (1, 4): 7, (2, 5): 8, (2, 4): 9, (4, 5): 8, (4, 4): 9}[(mf, nf)]
+        return bench.TILE_NAMES[(90 if mf == 4 else 100) + shape + (1000 if gn else 0)]
     m = re.search(r"idb_gemm_kernel(_rs|_pl)?I(DF16b|DF16_)Li(\d)ELi(\d)E(?:Li(\d)E)?(?:Li(\d)E)?", n)
     if m:
         wm = int(m.group(6) or 2)
