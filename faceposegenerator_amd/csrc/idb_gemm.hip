@@ -1776,6 +1776,8 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
         //    (M = 128) the 64x128 ring-3 tile with the same rule;
         //  * short K: 64-row ring-3 tiles, split only for tiny grids (the reduce launch costs more than a short K loop).
         const bool short_k = pl->ktiles <= 10;
+        const bool lin = d->nsrc == 1 && d->src[0].taps == 1;          // a plain linear / 1x1 conv
+        bool keep7 = false;                                            // a measured 64x128 plan: not narrowed to 64x64 below
         static const int plan_ab_early = [] { const char* e = getenv("IDB_GEMM_PLAN_AB"); return e ? atoi(e) : 0; }();
         if (d->n <= 32) tile = 5;
         else if (d->geglu && blocks_big >= 256) tile = pl->ktiles >= 16 ? 2 : 9;   // N = 8C, no split-K: 128-row (persistent form for K >= 1024)
@@ -1803,6 +1805,13 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
                 tile = n160 ? 8 : 9;
                 auto_sk = sk;
                 if (n160 && sk == 2 && pl->ktiles < 64) { tile = 6; auto_sk = 1; }   // 64x160: the same 256 workgroups without a reduce launch
+                else if (lin && sk <= 4 && pl->ktiles <= 48 && blocks64 >= 128 && blocks64 <= 256) {
+                    // a short split of a plain linear: 64x128 tiles fill more than half the chip without one — FF-out at 32x32 (M = 2048, N = 640,
+                    // K = 2560): 22.3 -> 16.7 us incl. the reduce launch it no longer needs (tools/bench_small.py)
+                    tile = 7;
+                    auto_sk = 1;
+                    keep7 = true;
+                }
             } else {
                 tile = 7;
                 sk = (int)(256 / blocks64);
@@ -1813,10 +1822,22 @@ int plan_gemm(const idb_gemm_desc* d, Plan* pl) {
             ring3 = 1;
         }
         else if (short_k && M >= 4096) { tile = (n160 && blocks_big < 256) ? 6 : 9; ring3 = tile == 6; }
+        else if (lin && short_k && M < 4096 && ((M + 127) / 128) * ((d->n + 127) / 128) >= 128 && ((M + 127) / 128) * ((d->n + 127) / 128) <= 256) {
+            // QKV at 32x32 (M = 2048, N = 1920, K = 640): 240 workgroups of 128x128 with loader waves instead of 480 of 64x128 two per CU:
+            // 13.9 -> 12.5 us (tools/bench_small.py)
+            tile = 9;
+            ring3 = 1;
+        }
+        else if (lin && n160 && pl->ktiles >= 16 && M >= 4096 && ((M + 63) / 64) * (d->n / 160) <= 256) {
+            // FF-out at 64x64 (M = 8192, N = 320, K = 1280): 256 workgroups of 64x160 with loader waves instead of 384 of 64x128 two per CU:
+            // 17.9 -> 14.1 us (tools/bench_small.py)
+            tile = 6;
+            ring3 = 1;
+        }
         else tile = (n160 && pl->ktiles >= 32) ? (M >= 4096 ? 6 : 3) : 7;
         if (tile == 7 && blocks64 <= 256) ring3 = 1;
         static const int env_ab = [] { const char* e = getenv("IDB_GEMM_PLAN_AB"); return e ? atoi(e) : 0; }();   // A/B switches for measurements
-        if (tile == 7 && blocks64 <= 160 && !d->geglu && !(env_ab & 1)) tile = 4;   // 64x64: twice the workgroups (m=512 n=1280 k=1280: 12.6 -> 9.9 us)
+        if (tile == 7 && blocks64 <= 160 && !d->geglu && !(env_ab & 1) && !keep7) tile = 4;   // 64x64: twice the workgroups (m=512 n=1280 k=1280: 12.6 -> 9.9 us)
     }
     if (d->geglu) IDB_REQUIRE(kTiles[tile].nf % 2 == 0, "idb_gemm: GEGLU needs an even-NF tile");
     if (d->tile == 0 && tile != 5) {
